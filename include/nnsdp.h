@@ -1,0 +1,164 @@
+/*
+ * nnsdp.h -- C ABI of the MI355X-native Chordal-DeepSDP assembler + ADMM solver.
+ *
+ * This is the drop-in boundary for the hot path of AntonXue/nn-sdp.  The reference has no FFI
+ * on this path; the seam is Julia multiple dispatch on the options type,
+ *     Methods.runQuery(query::Query, opts::QueryOptions)      src/Methods/Methods.jl:91-131
+ * which today builds a JuMP model (setupSafety!/setupReach!, src/Methods/deep_sdp.jl:10-61,
+ * src/Methods/chordal_sdp.jl:96-153) and hands it to MOSEK (Methods.jl:61,64,83).  A Julia
+ * method runQuery(query, opts::AdmmSdpOptions) ccall's nnsdp_solve() below instead
+ * (INTEGRATION.md shows the stub); the Python mirror in nn-sdp_amd/nnsdp_amd binds the same
+ * symbols through ctypes.
+ *
+ * Conventions: plain pointers and sizes only, caller owns every buffer, the library copies in,
+ * writes results into caller memory and retains nothing after a call returns (handles excepted,
+ * until destroyed).  All matrices are COLUMN-MAJOR Float64 (Julia layout).  Every function
+ * returns 0 on success, <0 for an invalid argument, >0 for a runtime (HIP/rocSOLVER/RCCL)
+ * failure; nnsdp_last_error() returns a thread-local message.  Nothing throws across the ABI.
+ * Blocking calls; distinct handles may be used from distinct threads, one handle from one
+ * thread at a time.
+ */
+#ifndef NNSDP_H
+#define NNSDP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNSDP_VERSION 100 /* 0.1.0 */
+
+/* query_kind: Methods.SafetyQuery / Methods.ReachQuery (src/Methods/Methods.jl:22-43) */
+enum { NNSDP_QUERY_SAFETY = 0, NNSDP_QUERY_REACH = 1 };
+/* out_kind: Qc.QcSafety / QcReachHplane / QcReachCircle / QcReachEllipsoid (src/Qc/output.jl:3-31) */
+enum { NNSDP_OUT_SAFETY_S = 0, NNSDP_OUT_HPLANE = 1, NNSDP_OUT_CIRCLE = 2, NNSDP_OUT_ELLIPSOID = 3 };
+/* decomp_mode: DeepSdpOptions (one dense cone, src/Methods/deep_sdp.jl:2-7) or
+ * ChordalSdpOptions.decomp_mode = SingleDecomp / DoubleDecomp (src/Methods/chordal_sdp.jl:4-16) */
+enum { NNSDP_DECOMP_DENSE = 0, NNSDP_DECOMP_SINGLE = 1, NNSDP_DECOMP_DOUBLE = 2 };
+/* termination status; strings as consumed by experiments/acas.jl:77 via nnsdp_status_string() */
+enum { NNSDP_STATUS_OPTIMAL = 0, NNSDP_STATUS_ITERATION_LIMIT = 1, NNSDP_STATUS_TIME_LIMIT = 2,
+       NNSDP_STATUS_SLOW_PROGRESS = 3, NNSDP_STATUS_NUMERICAL_ERROR = 4 };
+
+/*
+ * The numeric content of a Methods.Query: FeedFwdNet (src/MyNeuralNetwork/MyNeuralNetwork.jl:12-27),
+ * QcInputBox (src/Qc/input.jl:3-8), QcActivBounded (src/Qc/activ_bounded.jl:3-10),
+ * QcActivSector for ReLU (src/Qc/activ_sector.jl:2-20) and one QcOutput (src/Qc/output.jl:3-31).
+ */
+typedef struct nnsdp_problem {
+  int32_t K;              /* number of affine layers = length(ffnet.Ms) */
+  const int32_t* xdims;   /* K+1 layer sizes */
+  const double* M;        /* Ms[1..K] back to back, each xdims[k+1] x (xdims[k]+1) column-major = [W_k b_k] */
+  const double* x1min;    /* xdims[0] */
+  const double* x1max;    /* xdims[0] */
+  const double* acymin;   /* acdim = sum(xdims[1..K-1]) : QcActivBounded.acymin */
+  const double* acymax;   /* acdim */
+  const double* smin;     /* acdim : QcActivSector.smin (base_smin = 0) */
+  const double* smax;     /* acdim : QcActivSector.smax (base_smax = 1) */
+  int32_t beta;           /* QcActivSector.beta */
+  int32_t query_kind;     /* NNSDP_QUERY_* */
+  int32_t out_kind;       /* NNSDP_OUT_* */
+  const double* normal;   /* HPLANE: xdims[K] */
+  const double* yc;       /* CIRCLE / ELLIPSOID: xdims[K] */
+  const double* invP;     /* ELLIPSOID: xdims[K] x xdims[K] column-major */
+  const double* S;        /* SAFETY_S: (xdims[0]+xdims[K]+1)^2 column-major */
+} nnsdp_problem;
+
+/* The fields of `AdmmSdpOptions <: QueryOptions` (the replacement of ChordalSdpOptions). */
+typedef struct nnsdp_options {
+  int32_t decomp_mode;    /* NNSDP_DECOMP_* */
+  int32_t max_iters;      /* ADMM iteration cap (MOSEK analogue: MSK_IPAR_INTPNT_MAX_ITERATIONS) */
+  double eps_rel;         /* relative tolerance on both splitting residuals (INTPNT_CO_TOL_PFEAS/DFEAS) */
+  double max_time;        /* seconds; <= 0: none (MSK_DPAR_OPTIMIZER_MAX_TIME, experiments/scale.jl:32) */
+  double sigma;           /* initial ADMM penalty */
+  double alpha;           /* over-relaxation in (0,2) */
+  int32_t adapt_every;    /* residual-balancing period, iterations; 0 = fixed sigma */
+  int32_t check_every;    /* convergence-check period, iterations (= iterations per hipGraph launch) */
+  int32_t normalize;      /* 1: solver-internal interval congruence + fixed-neuron elimination (default) */
+  int32_t warm_start;     /* 1: warm-start each eigendecomposition from the previous eigenvectors */
+  int32_t verbose;        /* QueryOptions.verbose (src/Methods/Methods.jl:110) */
+  int32_t device;         /* HIP device ordinal, -1 = current */
+} nnsdp_options;
+
+/* Contents of Methods.QuerySolution (src/Methods/Methods.jl:46-55) plus solver diagnostics.
+ * gamma_* and Z are caller-allocated (any may be NULL to skip).  Sizes:
+ *   gamma_in xdims[0]; gamma_out 1 (reach only); gamma_ac1 acdim;
+ *   gamma_ac2 lambda_dim + 2*acdim, lambda_dim = (beta+1)*acdim - beta*(beta+1)/2;
+ *   Z Zdim x Zdim column-major, Zdim = sum(xdims[0..K-1]) + 1  (values[:Z], Methods.jl:86). */
+typedef struct nnsdp_result {
+  double* gamma_in;
+  double* gamma_out;
+  double* gamma_ac1;
+  double* gamma_ac2;
+  double* Z;
+  double objective;       /* objective_value */
+  int32_t status;         /* NNSDP_STATUS_* */
+  int32_t iters;
+  double pres;            /* |K x + q - w| / max(|K x + q|, |w|)      (dual feasibility of (P)) */
+  double dres;            /* |K'y - z0| / max(|K'y|, |z0|)           (LMI equality of (P)) */
+  double lambda_max;      /* eigmax(Z(gamma)) in the reference's coordinates (Methods.jl:116) */
+  double t_setup;         /* seconds: pattern + generators + factorisation (setup_time) */
+  double t_solve;         /* seconds: ADMM loop (solve_time) */
+  double t_total;         /* seconds (total_time) */
+  double t_eig;           /* seconds of t_solve inside the PSD-projection kernel (HIP events) */
+  int32_t n_cliques;      /* PSD blocks solved (after normalisation) */
+  int32_t max_clique;     /* largest block dimension solved */
+  int64_t eig_flops_per_iter; /* 10 * sum n_k^3 over the blocks solved */
+  int64_t eig_bytes_per_iter; /* 2 * 8 * sum n_k^2 */
+} nnsdp_result;
+
+int nnsdp_version(void);
+const char* nnsdp_last_error(void);
+const char* nnsdp_status_string(int32_t status);
+void nnsdp_default_options(nnsdp_options* opts);
+
+/* Sizes derived from a problem: Zdim, acdim, length of gamma_ac2, total length of gamma. */
+int nnsdp_problem_dims(const nnsdp_problem* p, int32_t* Zdim, int32_t* acdim, int32_t* nac2, int32_t* ngamma);
+
+/* Replaces Methods.runQuery's setup + solve (src/Methods/Methods.jl:91-131). */
+int nnsdp_solve(const nnsdp_problem* p, const nnsdp_options* o, nnsdp_result* r);
+
+/* Handle form of the same solve, used by bench.py to time exactly K iterations. */
+typedef struct nnsdp_solver nnsdp_solver;
+int nnsdp_solver_create(const nnsdp_problem* p, const nnsdp_options* o, nnsdp_solver** out);
+/* run `iters` ADMM iterations (no convergence test); eig_ms (may be NULL) receives the HIP-event
+ * time of the projection kernel summed over these iterations. */
+int nnsdp_solver_iterate(nnsdp_solver* s, int32_t iters, double* eig_ms);
+/* relative residuals and objectives of the current iterate */
+int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* pobj, double* dobj);
+/* iterate until converged / limits; fills r like nnsdp_solve */
+int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r);
+int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r);
+int nnsdp_solver_destroy(nnsdp_solver* s);
+
+/* Replaces Z = Zin + Zout + sum(Zacs) with numeric gamma: Qc.makeZin (src/Qc/input.jl:19-42),
+ * makeZout (src/Qc/output.jl:52-106), makeZac (src/Qc/activ.jl:30-42).  gamma = [gin; gout; gac1; gac2]
+ * (ngamma doubles); Z is Zdim x Zdim column-major.  Runs on the GPU. */
+int nnsdp_assemble_Z(const nnsdp_problem* p, const double* gamma, double* Z);
+
+/* Adjoint of the generator part: out[i] = <G_i, X> for every multiplier i (X symmetric Zdim x Zdim). */
+int nnsdp_adjoint(const nnsdp_problem* p, const double* X, double* out);
+
+/* Replaces Methods.makeCliques + the index sets used by setupZs!
+ * (src/Methods/chordal_cliques.jl:13-59, src/Methods/chordal_sdp.jl:19-57).  Two-pass:
+ * call with ptr == NULL to get n_cliques and total; then with ptr[n_cliques+1], idx[total]
+ * (0-based z-indices, CSR). */
+int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t decomp_mode,
+                       int32_t* n_cliques, int32_t* total, int32_t* ptr, int32_t* idx);
+
+/* Batched projection onto the PSD cone, the hot kernel (replaces the cone handling inside MOSEK;
+ * reference of the arithmetic: LinearAlgebra.eigen on Symmetric).  mats: `batch` symmetric
+ * matrices back to back, matrix b is n[b] x n[b] column-major, n[b] <= 128.  out receives the
+ * projections, eigvals (may be NULL) sum(n) eigenvalues.  in/out are HOST pointers. */
+int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mats, double* out,
+                              double* eigvals, double* kernel_ms);
+
+/* Multi-GPU (clique-sharded) mode: RCCL communicator over the ranks of one node.  The unique id
+ * is produced on rank 0 and distributed by the host launcher (torch.distributed in bench.py). */
+int nnsdp_comm_unique_id(char* id128);
+int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const char* id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNSDP_H */

@@ -1,0 +1,770 @@
+// C ABI of libnnsdp_hip.so (include/nnsdp.h): host orchestration of the HIP kernels.
+// One ADMM iteration = 6 kernels on one stream; `check_every` iterations are captured into a
+// hipGraph and replayed, so the host only touches the device once per convergence check.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/nnsdp.h"
+#include "kernels.hip"
+#include "setup.hpp"
+
+namespace nnsdp {
+
+thread_local std::string g_err;
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess)                                                                           \
+      throw HipError(std::string(#x) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" +    \
+                     std::to_string(__LINE__) + ")");                                               \
+  } while (0)
+#define RBCHK(x)                                                                                    \
+  do {                                                                                              \
+    rocblas_status s_ = (x);                                                                        \
+    if (s_ != rocblas_status_success)                                                               \
+      throw HipError(std::string(#x) + " failed: rocblas_status " + std::to_string((int)s_));       \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  ~DBuf() { if (p) (void)hipFree(p); }
+  void alloc(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count) HIPCHK(hipMalloc(&p, count * sizeof(T)));
+  }
+  void upload(const std::vector<T>& h) {
+    alloc(h.size());
+    if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void zero() { if (n) HIPCHK(hipMemset(p, 0, n * sizeof(T))); }
+  std::vector<T> download() const {
+    std::vector<T> h(n);
+    if (n) HIPCHK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+};
+
+static void require_gpu() {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    throw HipError("no HIP device available: libnnsdp_hip has no CPU fallback (the product path is GPU-only)");
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// device-resident operator (CSR + CSC + pattern)
+struct DevOperator {
+  int NE = 0, ng = 0, n = 0;
+  DBuf<int> csr_ptr, csr_col, csc_ptr, csc_row, erow, ecol;
+  DBuf<double> csr_val, csc_val, z0, c, Dinv;
+  void upload(const ScaledOperator& S, const Pattern& pat) {
+    NE = S.NE; ng = S.ng; n = pat.n;
+    csr_ptr.upload(S.csr_ptr); csr_col.upload(S.csr_col); csr_val.upload(S.csr_val);
+    csc_ptr.upload(S.csc_ptr); csc_row.upload(S.csc_row); csc_val.upload(S.csc_val);
+    z0.upload(S.z0); c.upload(S.c); Dinv.upload(S.Dinv);
+    erow.upload(pat.erow); ecol.upload(pat.ecol);
+  }
+};
+
+// reference-coordinates operator (dense pattern) for nnsdp_assemble_Z / nnsdp_adjoint / final Z
+struct FullOperator {
+  ProblemCopy P;
+  Pattern pat;
+  ScaledOperator S;
+  DevOperator D;
+  void build(const nnsdp_problem* p) {
+    P.load(p);
+    Congruence C = make_congruence(P, false);
+    pat = build_pattern(P.Zdim, {}, true);
+    Operator op = OperatorBuilder(P, C, pat).build();
+    S = scale_operator(op, false);
+    pat = std::move(op.pat);
+    D.upload(S, pat);
+  }
+  // Z (device, Zdim x Zdim column-major) from a full-length gamma (host)
+  void assemble(const std::vector<double>& gamma_full, DBuf<double>& Zd, hipStream_t st) {
+    std::vector<double> gk(S.ng);
+    for (int g = 0; g < S.ng; ++g) gk[g] = gamma_full[S.keep[g]];
+    DBuf<double> gd, zd;
+    gd.upload(gk);
+    zd.alloc(S.NE);
+    if (Zd.n != (size_t)P.Zdim * P.Zdim) Zd.alloc((size_t)P.Zdim * P.Zdim);
+    HIPCHK(hipMemsetAsync(Zd.p, 0, Zd.n * sizeof(double), st));
+    hipLaunchKernelGGL(k_apply_A, dim3(cdiv((long long)S.NE * 16, kThreads)), dim3(kThreads), 0, st, S.NE, D.csr_ptr.p,
+                       D.csr_col.p, D.csr_val.p, gd.p, D.z0.p, zd.p);
+    hipLaunchKernelGGL(k_scatter_dense, dim3(cdiv(S.NE, 256)), dim3(256), 0, st, S.NE, P.Zdim, D.erow.p, D.ecol.p, zd.p, Zd.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+  }
+};
+
+struct RocHandle {
+  rocblas_handle h = nullptr;
+  RocHandle() { RBCHK(rocblas_create_handle(&h)); }
+  ~RocHandle() { if (h) rocblas_destroy_handle(h); }
+};
+
+static double lambda_max_dense(rocblas_handle h, const DBuf<double>& Zd, int n, double* lambda_min = nullptr) {
+  DBuf<double> A, D, E;
+  DBuf<rocblas_int> info;
+  A.alloc((size_t)n * n); D.alloc(n); E.alloc(n); info.alloc(1);
+  HIPCHK(hipMemcpy(A.p, Zd.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice));
+  RBCHK(rocsolver_dsyevd(h, rocblas_evect_none, rocblas_fill_lower, n, A.p, n, D.p, E.p, info.p));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<double> d = D.download();
+  if (lambda_min) *lambda_min = d.front();
+  return d.back();
+}
+
+__global__ void k_symmetrize_lower(int n, int ld, double* A) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n && i > j) A[(size_t)i * ld + j] = A[(size_t)j * ld + i];  // copy lower (col j,row i) to upper
+}
+
+}  // namespace nnsdp
+
+using namespace nnsdp;
+
+struct nnsdp_solver {
+  nnsdp_options opt;
+  ProblemCopy P;
+  Congruence C;
+  Pattern pat;
+  ScaledOperator S;
+  DevOperator D;
+  std::vector<int> cn;
+  std::vector<long long> coff;
+  long long nmat = 0;
+  int ncl = 0, nmax = 0;
+  bool v_lds = true;
+  size_t lds_bytes = 0;
+  int ldm = 0;
+  // device state
+  DBuf<int> d_cn, d_sptr, d_stats;
+  DBuf<long long> d_coff, d_soff;
+  DBuf<unsigned char> d_isdiag;
+  DBuf<unsigned int> d_gidx;
+  DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc, gs;
+  double sigma = 1.0;
+  hipStream_t st = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  int graph_iters = 0;
+  std::vector<hipEvent_t> ev;
+  std::unique_ptr<RocHandle> roc;
+  long long iters_done = 0;
+  int since_cold = 0;
+  double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
+  double last_pres = 1e300, last_dres = 1e300, last_pobj = 0, last_dobj = 0;
+  std::unique_ptr<FullOperator> full;
+
+  ~nnsdp_solver() {
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  double* d_sigma() { return scal.p; }
+  double* d_kappa() { return scal.p + 1; }
+
+  void setup(const nnsdp_problem* prob, const nnsdp_options* o) {
+    t_create0 = now_s();
+    opt = *o;
+    if (opt.max_iters <= 0) throw std::invalid_argument("max_iters must be > 0");
+    if (!(opt.alpha > 0.0 && opt.alpha < 2.0)) throw std::invalid_argument("alpha must be in (0,2)");
+    if (!(opt.sigma > 0.0)) throw std::invalid_argument("sigma must be > 0");
+    if (opt.check_every <= 0) opt.check_every = 50;
+    if (opt.decomp_mode < NNSDP_DECOMP_DENSE || opt.decomp_mode > NNSDP_DECOMP_DOUBLE)
+      throw std::invalid_argument("unrecognized decomp_mode");
+    P.load(prob);
+    require_gpu();
+    if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
+    HIPCHK(hipStreamCreate(&st));
+    C = make_congruence(P, opt.normalize != 0);
+    auto cl_full = clique_index_sets(P.K, P.xdims.data(), P.beta, opt.decomp_mode);
+    std::vector<std::vector<int>> cl;
+    for (auto& cq : cl_full) {
+      std::vector<int> r;
+      for (int i : cq)
+        if (C.newpos[i] >= 0) r.push_back(C.newpos[i]);
+      std::sort(r.begin(), r.end());
+      r.erase(std::unique(r.begin(), r.end()), r.end());
+      // identical index sets constrain the same block: a sum of NSD matrices on one index set is
+      // NSD, so one block per distinct set is an equivalent feasible set
+      if (std::find(cl.begin(), cl.end(), r) == cl.end()) cl.push_back(r);
+    }
+    Pattern pt = build_pattern(C.nred, cl);
+    Operator op = OperatorBuilder(P, C, pt).build();
+    S = scale_operator(op, opt.normalize != 0);
+    pat = std::move(op.pat);
+    D.upload(S, pat);
+    ncl = (int)pat.cliques.size();
+    cn.resize(ncl);
+    coff.resize(ncl + 1);
+    nmat = 0;
+    nmax = 0;
+    for (int k = 0; k < ncl; ++k) {
+      cn[k] = (int)pat.cliques[k].size();
+      coff[k] = nmat;
+      nmat += (long long)cn[k] * cn[k];
+      nmax = std::max(nmax, cn[k]);
+    }
+    coff[ncl] = nmat;
+    if (nmax > 128 && opt.decomp_mode != NNSDP_DECOMP_DENSE)
+      throw std::invalid_argument("clique larger than 128 is not supported by the LDS-resident projection kernel");
+    if (nmax > 128) throw std::invalid_argument("dense mode supports Zdim <= 128 only (use a chordal decomp_mode)");
+    v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
+    lds_bytes = proj_lds_bytes(nmax, v_lds);
+    // gather sources: entry e <- (clique k, lower element (i,j))
+    std::vector<int> sptr(S.NE + 1, 0);
+    for (int k = 0; k < ncl; ++k) {
+      auto& cq = pat.cliques[k];
+      for (int j = 0; j < cn[k]; ++j)
+        for (int i = j; i < cn[k]; ++i) sptr[pat.pos(cq[i], cq[j]) + 1]++;
+    }
+    for (int e = 0; e < S.NE; ++e) sptr[e + 1] += sptr[e];
+    std::vector<long long> soff(sptr[S.NE]);
+    {
+      std::vector<int> fill(sptr.begin(), sptr.end() - 1);
+      for (int k = 0; k < ncl; ++k) {
+        auto& cq = pat.cliques[k];
+        for (int j = 0; j < cn[k]; ++j)
+          for (int i = j; i < cn[k]; ++i) soff[fill[pat.pos(cq[i], cq[j])]++] = coff[k] + (long long)j * cn[k] + i;
+      }
+    }
+    std::vector<unsigned char> isdiag(S.NE);
+    for (int e = 0; e < S.NE; ++e) isdiag[e] = pat.erow[e] == pat.ecol[e];
+    std::vector<unsigned int> gidx(nmat);
+    for (int k = 0; k < ncl; ++k) {
+      auto& cq = pat.cliques[k];
+      for (int j = 0; j < cn[k]; ++j)
+        for (int i = 0; i < cn[k]; ++i)
+          gidx[coff[k] + (long long)j * cn[k] + i] = (unsigned)pat.pos(cq[i], cq[j]) | (i == j ? 0x80000000u : 0u);
+    }
+    d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
+    d_isdiag.upload(isdiag); d_gidx.upload(gidx);
+    d_stats.alloc(2); d_stats.zero();
+    // M^-1 on the device (rocSOLVER potrf + potri; one-time plain-library factorisation)
+    roc.reset(new RocHandle());
+    RBCHK(rocblas_set_stream(roc->h, st));
+    int ng = S.ng;
+    ldm = (ng + 1) & ~1;
+    {
+      std::vector<double> M;
+      build_M(S, M);
+      Minv.alloc((size_t)ldm * std::max(ng, 1));
+      Minv.zero();
+      HIPCHK(hipMemcpy2D(Minv.p, (size_t)ldm * sizeof(double), M.data(), (size_t)ng * sizeof(double), (size_t)ng * sizeof(double),
+                         ng, hipMemcpyHostToDevice));
+    }
+    DBuf<rocblas_int> info;
+    info.alloc(1);
+    RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
+    RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
+    hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(ng, 256), ng), dim3(256), 0, st, ng, ldm, Minv.p);
+    HIPCHK(hipStreamSynchronize(st));
+    if (info.download()[0] != 0) throw HipError("Cholesky of M = I + A'D^-1A failed (info != 0)");
+    // iteration state
+    nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
+    x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
+    scal.alloc(2); acc.alloc(8);
+    nu.zero(); w.zero(); Vg.zero(); x.zero(); g.zero(); qv.zero();
+    {
+      std::vector<double> s0(ng);
+      for (int i = 0; i < ng; ++i) s0[i] = std::max(S.c[i], 0.0);
+      HIPCHK(hipMemcpy(nu.p, s0.data(), ng * sizeof(double), hipMemcpyHostToDevice));
+    }
+    sigma = opt.sigma;
+    double sc[2] = {sigma, 1.0};
+    HIPCHK(hipMemcpy(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice));
+    if (lds_bytes > 64 * 1024) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    t_setup = now_s() - t_create0;
+  }
+
+  void launch_proj(bool warm) {
+    ProjArgs a;
+    a.cn = d_cn.p; a.coff = d_coff.p; a.eoff = nullptr;
+    a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr;
+    a.kappa = d_kappa(); a.stats = d_stats.p;
+    a.warm = warm ? 1 : 0;
+    a.max_sweeps = 15;
+    a.tol = 1e-13;
+    if (v_lds) hipLaunchKernelGGL(k_proj_jacobi<true>, dim3(ncl), dim3(kThreads), lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_proj_jacobi<false>, dim3(ncl), dim3(kThreads), lds_bytes, st, a);
+  }
+
+  // enqueue one iteration on the stream; check=true also accumulates the residual sums
+  void enqueue_iteration(bool check, bool warm, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    int ng = S.ng, NE = S.NE;
+    if (e0) HIPCHK(hipEventRecord(e0, st));
+    launch_proj(warm);
+    if (e1) HIPCHK(hipEventRecord(e1, st));
+    hipLaunchKernelGGL(k_gather_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
+                       nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p);
+    hipLaunchKernelGGL(k_spmv_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, D.csc_ptr.p, D.csc_row.p,
+                       D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
+    if (check) {
+      HIPCHK(hipMemsetAsync(acc.p, 0, 8 * sizeof(double), st));
+      hipLaunchKernelGGL(k_check_dual, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, ng, D.csr_ptr.p,
+                         D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p);
+    }
+    hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
+    hipLaunchKernelGGL(k_spmv_A_x, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, D.csr_ptr.p, D.csr_col.p,
+                       D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p);
+    if (check)
+      hipLaunchKernelGGL(k_check_obj, dim3(cdiv(std::max(ng, NE), kThreads)), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p,
+                         x.p, d_sigma(), acc.p);
+    hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
+                       d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr);
+    HIPCHK(hipGetLastError());
+  }
+
+  // a cold eigendecomposition every kColdPeriod iterations bounds the drift of the warm basis
+  static constexpr int kColdPeriod = 64;
+  static constexpr int kGraphIters = 8;
+  bool next_is_warm() {
+    bool warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
+    since_cold = warm ? since_cold + 1 : 1;
+    return warm;
+  }
+
+  void build_graph(int n_iters) {
+    if (gexec && graph_iters == n_iters) return;
+    if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < n_iters; ++i) enqueue_iteration(false, opt.warm_start != 0);
+    HIPCHK(hipStreamEndCapture(st, &graph));
+    HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    graph_iters = n_iters;
+  }
+
+  // run n plain iterations; timed=true launches eagerly with HIP events around the projection kernel
+  void iterate(int n, double* eig_ms) {
+    if (n <= 0) return;
+    if (eig_ms) {
+      while ((int)ev.size() < 2 * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
+      for (int i = 0; i < n; ++i) { enqueue_iteration(false, next_is_warm(), ev[2 * i], ev[2 * i + 1]); ++iters_done; }
+      HIPCHK(hipStreamSynchronize(st));
+      double tot = 0;
+      for (int i = 0; i < n; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+      *eig_ms = tot;
+      t_eig += tot * 1e-3;
+      return;
+    }
+    // hipGraph replay of kGraphIters warm iterations at a time; cold iterations and remainders eagerly
+    int left = n;
+    while (left > 0) {
+      bool can_warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
+      if (can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
+        build_graph(kGraphIters);
+        HIPCHK(hipGraphLaunch(gexec, st));
+        since_cold += kGraphIters; iters_done += kGraphIters; left -= kGraphIters;
+      } else {
+        enqueue_iteration(false, next_is_warm());
+        ++iters_done; --left;
+      }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+  }
+
+  // one iteration with residual accumulation; fills last_*
+  void check_iteration() {
+    enqueue_iteration(true, next_is_warm());
+    ++iters_done;
+    double a[8];
+    HIPCHK(hipMemcpyAsync(a, acc.p, sizeof(a), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double z0n = 0;  // |z0| (scaled) is 1 when normalised; compute anyway
+    for (double v : S.z0) z0n += v * v;
+    z0n = std::sqrt(z0n);
+    last_pres = std::sqrt(a[0]) / std::max({std::sqrt(a[1]), std::sqrt(a[2]), 1e-300});
+    last_dres = std::sqrt(a[3]) / std::max({std::sqrt(a[4]), z0n, 1e-300});
+    last_pobj = a[5] / (S.zscale * S.cscale);
+    last_dobj = a[6] / (S.zscale * S.cscale);
+  }
+
+  void set_sigma(double ns) {
+    double sc[2] = {ns, sigma / ns};
+    HIPCHK(hipMemcpyAsync(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    sigma = ns;
+  }
+
+  int run_loop() {
+    double t0 = now_s();
+    int status = NNSDP_STATUS_ITERATION_LIMIT;
+    int ce = opt.check_every;
+    while (iters_done < opt.max_iters) {
+      int n = (int)std::min<long long>(ce - 1, opt.max_iters - iters_done - 1);
+      iterate(n, nullptr);
+      check_iteration();
+      if (opt.verbose)
+        std::fprintf(stderr, "[nnsdp] it %6lld pres %.3e dres %.3e obj %.8g dobj %.8g sigma %.3g\n", iters_done, last_pres,
+                     last_dres, last_pobj, last_dobj, sigma);
+      if (!(last_pres == last_pres) || !(last_dres == last_dres)) { status = NNSDP_STATUS_NUMERICAL_ERROR; break; }
+      if (last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
+      if (opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
+      if (opt.adapt_every > 0 && (iters_done / ce) % std::max(1, opt.adapt_every / ce) == 0) {
+        double ratio = std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
+        if (ratio > 2.0 || ratio < 0.5) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
+      }
+    }
+    t_solve += now_s() - t0;
+    return status;
+  }
+
+  void finish(nnsdp_result* r, int status) {
+    int ng = S.ng;
+    hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(ng, 256)), dim3(256), 0, st, ng, nu.p, d_sigma(), gs.p);
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<double> gsh = gs.download();
+    std::vector<double> gam(P.ng, 0.0);
+    for (int i = 0; i < ng; ++i) gam[S.keep[i]] = gsh[i] * S.ecol[i] / S.zscale;
+    // final Z and certificate in the reference's coordinates
+    if (!full) {
+      full.reset(new FullOperator());
+      nnsdp_problem pp = problem_view();
+      full->build(&pp);
+    }
+    std::vector<int> elim;  // neurons removed by the normalisation: gac1 -> "large enough"
+    if (opt.normalize && P.query_kind == NNSDP_QUERY_REACH)
+      for (int t = 0; t < P.acdim; ++t)
+        if (C.newpos[P.nin + t] < 0) elim.push_back(t);
+    DBuf<double> Zd;
+    double lmax = 0;
+    double gscale = 1.0;
+    for (double v : gam) gscale = std::max(gscale, v);
+    // multipliers of eliminated neurons are cost-free: raise them until eigmax(Z) stops improving
+    double best_l = 1e300, best_big = 0.0, prev_l = 1e300;
+    int ntrial = elim.empty() ? 1 : 6;
+    for (int trial = 0; trial < ntrial; ++trial) {
+      double big = elim.empty() ? 0.0 : gscale * std::pow(100.0, trial + 1);
+      for (int t : elim) gam[P.nin + P.nout + t] = big;
+      full->assemble(gam, Zd, st);
+      lmax = lambda_max_dense(roc->h, Zd, P.Zdim);
+      if (lmax < best_l) { best_l = lmax; best_big = big; }
+      if (lmax <= 1e-7 || (trial > 0 && lmax >= 0.9 * prev_l)) break;
+      prev_l = lmax;
+    }
+    if (!elim.empty() && gam[P.nin + P.nout + elim[0]] != best_big) {
+      for (int t : elim) gam[P.nin + P.nout + t] = best_big;
+      full->assemble(gam, Zd, st);
+      lmax = lambda_max_dense(roc->h, Zd, P.Zdim);
+    }
+    const double* gp = gam.data();
+    if (r->gamma_in) std::memcpy(r->gamma_in, gp, P.nin * sizeof(double));
+    if (r->gamma_out && P.nout) r->gamma_out[0] = gp[P.nin];
+    if (r->gamma_ac1) std::memcpy(r->gamma_ac1, gp + P.nin + P.nout, P.n1 * sizeof(double));
+    if (r->gamma_ac2) std::memcpy(r->gamma_ac2, gp + P.nin + P.nout + P.n1, P.n2 * sizeof(double));
+    if (r->Z) HIPCHK(hipMemcpy(r->Z, Zd.p, (size_t)P.Zdim * P.Zdim * sizeof(double), hipMemcpyDeviceToHost));
+    double obj = 0;
+    if (P.nout) obj = gam[P.nin];
+    else for (double v : gam) obj += v;
+    r->objective = obj;
+    r->status = status;
+    r->iters = (int)iters_done;
+    r->pres = last_pres;
+    r->dres = last_dres;
+    r->lambda_max = lmax;
+    r->t_setup = t_setup;
+    r->t_solve = t_solve;
+    r->t_total = now_s() - t_create0;
+    r->t_eig = t_eig;
+    r->n_cliques = ncl;
+    r->max_clique = nmax;
+    long long f = 0, b = 0;
+    for (int k = 0; k < ncl; ++k) { f += 10LL * cn[k] * cn[k] * cn[k]; b += 16LL * cn[k] * cn[k]; }
+    r->eig_flops_per_iter = f;
+    r->eig_bytes_per_iter = b;
+  }
+
+  // a nnsdp_problem view over the deep copy (column-major M rebuilt)
+  std::vector<double> Mpack;
+  nnsdp_problem problem_view() {
+    Mpack.clear();
+    for (int k = 0; k < P.K; ++k) {
+      int r = P.xdims[k + 1], c = P.xdims[k];
+      for (int j = 0; j < c; ++j)
+        for (int i = 0; i < r; ++i) Mpack.push_back(P.W[k][(size_t)i * c + j]);
+      for (int i = 0; i < r; ++i) Mpack.push_back(P.b[k][i]);
+    }
+    nnsdp_problem pp{};
+    pp.K = P.K; pp.xdims = P.xdims.data(); pp.M = Mpack.data();
+    pp.x1min = P.x1min.data(); pp.x1max = P.x1max.data(); pp.acymin = P.acymin.data(); pp.acymax = P.acymax.data();
+    pp.smin = P.smin.data(); pp.smax = P.smax.data(); pp.beta = P.beta; pp.query_kind = P.query_kind; pp.out_kind = P.out_kind;
+    pp.normal = P.normal.empty() ? nullptr : P.normal.data();
+    pp.yc = P.yc.empty() ? nullptr : P.yc.data();
+    pp.invP = P.invP.empty() ? nullptr : P.invP.data();
+    pp.S = P.S.empty() ? nullptr : P.S.data();
+    return pp;
+  }
+};
+
+// ------------------------------------------------------------------------------------------ ABI
+#define API_BEGIN try {
+#define API_END                                                                    \
+  }                                                                                \
+  catch (const std::invalid_argument& e) { g_err = e.what(); return -1; }          \
+  catch (const HipError& e) { g_err = e.what(); return 2; }                        \
+  catch (const std::bad_alloc&) { g_err = "out of host memory"; return 3; }        \
+  catch (const std::exception& e) { g_err = e.what(); return 1; }                  \
+  catch (...) { g_err = "unknown error"; return 1; }                               \
+  return 0;
+
+extern "C" {
+
+int nnsdp_version(void) { return NNSDP_VERSION; }
+const char* nnsdp_last_error(void) { return g_err.c_str(); }
+
+const char* nnsdp_status_string(int32_t s) {
+  switch (s) {
+    case NNSDP_STATUS_OPTIMAL: return "OPTIMAL";
+    case NNSDP_STATUS_ITERATION_LIMIT: return "ITERATION_LIMIT";
+    case NNSDP_STATUS_TIME_LIMIT: return "TIME_LIMIT";
+    case NNSDP_STATUS_SLOW_PROGRESS: return "SLOW_PROGRESS";
+    case NNSDP_STATUS_NUMERICAL_ERROR: return "NUMERICAL_ERROR";
+    default: return "UNKNOWN";
+  }
+}
+
+void nnsdp_default_options(nnsdp_options* o) {
+  if (!o) return;
+  o->decomp_mode = NNSDP_DECOMP_SINGLE;
+  o->max_iters = 20000;
+  o->eps_rel = 1e-6;
+  o->max_time = 0.0;
+  o->sigma = 0.1;
+  o->alpha = 1.6;
+  o->adapt_every = 50;
+  o->check_every = 50;
+  o->normalize = 1;
+  o->warm_start = 1;
+  o->verbose = 0;
+  o->device = -1;
+}
+
+int nnsdp_problem_dims(const nnsdp_problem* p, int32_t* Zdim, int32_t* acdim, int32_t* nac2, int32_t* ngamma) {
+  API_BEGIN
+  if (!p || !p->xdims) throw std::invalid_argument("null problem");
+  if (p->K < 2) throw std::invalid_argument("K must be >= 2");
+  int z = 1, ac = 0;
+  for (int k = 0; k < p->K; ++k) z += p->xdims[k];
+  for (int k = 1; k < p->K; ++k) ac += p->xdims[k];
+  int beta = p->beta;
+  if (beta < 0 || beta > ac) throw std::invalid_argument("beta out of range");
+  int n2 = (beta + 1) * ac - beta * (beta + 1) / 2 + 2 * ac;
+  if (Zdim) *Zdim = z;
+  if (acdim) *acdim = ac;
+  if (nac2) *nac2 = n2;
+  if (ngamma) *ngamma = p->xdims[0] + (p->query_kind == NNSDP_QUERY_REACH ? 1 : 0) + ac + n2;
+  API_END
+}
+
+int nnsdp_solver_create(const nnsdp_problem* p, const nnsdp_options* o, nnsdp_solver** out) {
+  API_BEGIN
+  if (!p || !o || !out) throw std::invalid_argument("null argument");
+  std::unique_ptr<nnsdp_solver> s(new nnsdp_solver());
+  s->setup(p, o);
+  *out = s.release();
+  API_END
+}
+
+int nnsdp_solver_iterate(nnsdp_solver* s, int32_t iters, double* eig_ms) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  if (iters < 0) throw std::invalid_argument("iters must be >= 0");
+  double t0 = now_s();
+  s->iterate(iters, eig_ms);
+  s->t_solve += now_s() - t0;
+  API_END
+}
+
+int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* pobj, double* dobj) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  s->check_iteration();
+  if (pres) *pres = s->last_pres;
+  if (dres) *dres = s->last_dres;
+  if (pobj) *pobj = s->last_pobj;
+  if (dobj) *dobj = s->last_dobj;
+  API_END
+}
+
+int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r) {
+  API_BEGIN
+  if (!s || !r) throw std::invalid_argument("null argument");
+  int status = s->run_loop();
+  s->finish(r, status);
+  API_END
+}
+
+int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r) {
+  API_BEGIN
+  if (!s || !r) throw std::invalid_argument("null argument");
+  int status = (s->last_pres <= s->opt.eps_rel && s->last_dres <= s->opt.eps_rel) ? NNSDP_STATUS_OPTIMAL : NNSDP_STATUS_ITERATION_LIMIT;
+  s->finish(r, status);
+  API_END
+}
+
+int nnsdp_solver_destroy(nnsdp_solver* s) {
+  API_BEGIN
+  delete s;
+  API_END
+}
+
+int nnsdp_solve(const nnsdp_problem* p, const nnsdp_options* o, nnsdp_result* r) {
+  API_BEGIN
+  if (!p || !o || !r) throw std::invalid_argument("null argument");
+  std::unique_ptr<nnsdp_solver> s(new nnsdp_solver());
+  s->setup(p, o);
+  int status = s->run_loop();
+  s->finish(r, status);
+  API_END
+}
+
+int nnsdp_assemble_Z(const nnsdp_problem* p, const double* gamma, double* Z) {
+  API_BEGIN
+  if (!p || !gamma || !Z) throw std::invalid_argument("null argument");
+  require_gpu();
+  FullOperator F;
+  F.build(p);
+  std::vector<double> g(gamma, gamma + F.P.ng);
+  DBuf<double> Zd;
+  F.assemble(g, Zd, nullptr);
+  HIPCHK(hipMemcpy(Z, Zd.p, Zd.n * sizeof(double), hipMemcpyDeviceToHost));
+  API_END
+}
+
+int nnsdp_adjoint(const nnsdp_problem* p, const double* X, double* out) {
+  API_BEGIN
+  if (!p || !X || !out) throw std::invalid_argument("null argument");
+  require_gpu();
+  FullOperator F;
+  F.build(p);
+  int n = F.P.Zdim, NE = F.S.NE, ng = F.S.ng;
+  DBuf<double> Xd, xv, od;
+  Xd.alloc((size_t)n * n);
+  HIPCHK(hipMemcpy(Xd.p, X, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+  xv.alloc(NE);
+  od.alloc(ng);
+  hipLaunchKernelGGL(k_gather_dense, dim3(cdiv(NE, 256)), dim3(256), 0, nullptr, NE, n, F.D.erow.p, F.D.ecol.p, Xd.p, xv.p);
+  hipLaunchKernelGGL(k_apply_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, nullptr, ng, F.D.csc_ptr.p, F.D.csc_row.p,
+                     F.D.csc_val.p, xv.p, od.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<double> o = od.download();
+  for (int g = 0; g < F.P.ng; ++g) out[g] = 0.0;
+  for (int g = 0; g < ng; ++g) out[F.S.keep[g]] = o[g];
+  API_END
+}
+
+int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t mode, int32_t* n_cliques, int32_t* total,
+                       int32_t* ptr, int32_t* idx) {
+  API_BEGIN
+  if (!xdims || K < 2) throw std::invalid_argument("bad xdims / K");
+  if (beta < 0) throw std::invalid_argument("beta must be >= 0");
+  if (mode < NNSDP_DECOMP_DENSE || mode > NNSDP_DECOMP_DOUBLE) throw std::invalid_argument("unrecognized decomp_mode");
+  auto cl = clique_index_sets(K, xdims, beta, mode);
+  int tot = 0;
+  for (auto& c : cl) tot += (int)c.size();
+  if (n_cliques) *n_cliques = (int)cl.size();
+  if (total) *total = tot;
+  if (ptr && idx) {
+    int o = 0;
+    for (size_t k = 0; k < cl.size(); ++k) {
+      ptr[k] = o;
+      for (int v : cl[k]) idx[o++] = v;
+    }
+    ptr[cl.size()] = o;
+  }
+  API_END
+}
+
+int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mats, double* out, double* eigvals, double* kernel_ms) {
+  API_BEGIN
+  if (batch < 0) throw std::invalid_argument("batch must be >= 0");
+  if (batch == 0) return 0;
+  if (!n || !mats || !out) throw std::invalid_argument("null argument");
+  require_gpu();
+  std::vector<int> cn(n, n + batch);
+  std::vector<long long> coff(batch + 1), eoff(batch + 1);
+  long long tot = 0, etot = 0;
+  int nmax = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (cn[b] < 1 || cn[b] > 128) throw std::invalid_argument("matrix dimension must be in 1..128");
+    coff[b] = tot; eoff[b] = etot;
+    tot += (long long)cn[b] * cn[b]; etot += cn[b];
+    nmax = std::max(nmax, cn[b]);
+  }
+  coff[batch] = tot; eoff[batch] = etot;
+  DBuf<int> dcn; DBuf<long long> dco, deo; DBuf<double> dnu, dw, dV, dE;
+  dcn.upload(cn); dco.upload(coff); deo.upload(eoff);
+  dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dE.alloc(etot);
+  HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
+  bool v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
+  size_t lds = proj_lds_bytes(nmax, v_lds);
+  if (lds > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  ProjArgs a;
+  a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
+  a.kappa = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-15;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, nullptr));
+  if (v_lds) hipLaunchKernelGGL(k_proj_jacobi<true>, dim3(batch), dim3(kThreads), lds, nullptr, a);
+  else hipLaunchKernelGGL(k_proj_jacobi<false>, dim3(batch), dim3(kThreads), lds, nullptr, a);
+  HIPCHK(hipEventRecord(e1, nullptr));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (kernel_ms) *kernel_ms = ms;
+  HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+  if (eigvals) HIPCHK(hipMemcpy(eigvals, dE.p, etot * sizeof(double), hipMemcpyDeviceToHost));
+  API_END
+}
+
+int nnsdp_comm_unique_id(char* id128) {
+  (void)id128;
+  g_err = "clique-sharded multi-GPU mode is not built in this version (bench.py --gpus N runs independent SDPs per rank)";
+  return 1;
+}
+
+int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const char* id128) {
+  (void)s; (void)nranks; (void)rank; (void)id128;
+  g_err = "clique-sharded multi-GPU mode is not built in this version (bench.py --gpus N runs independent SDPs per rank)";
+  return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+"""nnsdp_amd: MI355X-native Chordal-DeepSDP LMI assembler + ADMM solver (host-side mirror of the
+reference's Methods/Qc API over the C ABI in include/nnsdp.h)."""
+from .methods import (  # noqa: F401
+    FeedFwdNet, QcInputBox, QcSafety, QcReachHplane, QcReachCircle, QcReachEllipsoid,
+    QcActivBounded, QcActivSector, SafetyQuery, ReachQuery, AdmmSdpOptions, QuerySolution,
+    SingleDecomp, DoubleDecomp, DenseCone, Solver,
+    runQuery, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched,
+)
+from . import _lib  # noqa: F401
+
+__version__ = "0.1.0"
