@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ADMM iterations/s of the chordal SDP solve on bench/rand W=40 D=20.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
+torch.distributed.run, one rank per GPU.  One JSON line on rank 0.
+
+  * step   = one ADMM iteration (per-clique PSD projection + consensus/multiplier updates) over the
+             whole SDP, all data resident in HBM before the timed region.
+  * N = 1  : workload = BASELINE.json configs[2], "bench/rand W=40 D=20, full chordal decomposition,
+             all cliques batched on 1 x MI355X" (fixture tests/golden/problem_W40-D20_b0.npz).
+  * N > 1  : weak scaling over INDEPENDENT SDPs (one per rank, no data-path collective); value is the
+             aggregate iterations/s.  See DESIGN.md "Multi-GPU".
+  * roofline: the projection kernel is compute bound (fp64), so `bound` = "mfma" with the fp64
+             vector/matrix peak; achieved = algorithmic flops (10 * sum n_k^3 of the blocks solved)
+             / average kernel duration from HIP events recorded on the solver's stream inside the
+             timed region.  The HBM-side figures the north star asks for are reported as hbm_*.
+  * cpu_baseline: the numpy oracle (same ADMM, LAPACK eigh) timed on the host for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "nn-sdp_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = fp64 matrix peak (half the fp32 vector peak of 157.3)
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(workload: str, beta: int, seconds: float):
+    """oracle ADMM (numpy, LAPACK eigh per clique) timed on the host cores: a reported baseline."""
+    import helpers
+    from oracle import operator as oop, admm as oadmm
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    cores = min(16, os.cpu_count() or 1)
+    d = helpers.load_problem(workload, beta)
+    q = helpers.oracle_query(d)
+    L = oop.build_operator(q, "single", normalize=True)
+
+    def run():
+        P = oadmm.ScaledProblem(L)
+        S = oadmm.AdmmState(P, 0.1, 1.6)
+        for _ in range(3):
+            S.step()
+        n, t0 = 0, time.time()
+        while time.time() - t0 < seconds:
+            S.step()
+            n += 1
+        return n, time.time() - t0
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=cores):
+            n, dt = run()
+    else:
+        n, dt = run()
+    return {"value": n / dt, "unit": "ADMM iters/s", "cores": cores, "kind": "port",
+            "sample": f"{n} iterations of the numpy oracle ADMM (oracle/admm.py, LAPACK eigh per clique) on {workload} beta={beta} in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="W40-D20")
+    ap.add_argument("--beta", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cert-seconds", type=float, default=30.0, help="time cap of the time-to-certificate solve (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import helpers
+    import nnsdp_amd as na
+    d = helpers.load_problem(args.workload, args.beta)
+    q = helpers.product_query(d)
+    opts = na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9, device=local_rank)
+    solver = na.Solver(q, opts)           # setup: pattern, generators, factorisation; everything now in HBM
+    solver.iterate(args.warmup, time_eig=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    eig_ms = solver.iterate(args.steps, time_eig=True)   # eager launches + HIP events around the projection kernel
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pres, dres, pobj, dobj = solver.residuals()
+    soln = solver.finish()
+    sm = soln.summary
+
+    # hipGraph replay rate of the same iteration (what nnsdp_solve itself uses)
+    tg0 = time.perf_counter()
+    solver.iterate(args.steps)
+    torch.cuda.synchronize()
+    graph_ips = args.steps / (time.perf_counter() - tg0)
+    solver.close()
+
+    out = None
+    if rank == 0:
+        eig_avg_s = eig_ms * 1e-3 / args.steps
+        flops = float(sm["eig_flops_per_iter"])
+        byts = float(sm["eig_bytes_per_iter"])
+        ach_tf = flops / eig_avg_s / 1e12
+        out = {
+            "metric": "ADMM iters/sec + wall-clock to eps-cert, bench/rand W=40 D=20",
+            "value": world * args.steps / dt,
+            "unit": "ADMM iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "reference bench/rand random network (fixture), CROWN-sliced intervals and sampled ellipsoid precomputed on the host",
+            "config": {"workload": f"bench/rand scale-I2-O2-{args.workload} beta={args.beta}, findEllipsoid on [0.5,1.5]^2, "
+                                   f"chordal SingleDecomp, {sm['n_cliques']} PSD blocks (max n={sm['max_clique']}) on 1 GPU"
+                                   + ("" if world == 1 else f"; {world} independent SDPs, one per GPU"),
+                       "parallelism": "1 SDP per GPU, cliques batched in one launch"},
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_proj_jacobi", "kernel_avg_us": eig_avg_s * 1e6,
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+                         "hbm_achieved_GBs": byts / eig_avg_s / 1e9, "hbm_frac": byts / eig_avg_s / 1e9 / HBM_PEAK_GBS},
+            "eig_share_of_step": eig_avg_s / (dt / args.steps),
+            "graph_replay_iters_per_s": graph_ips,
+            "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
+        }
+    if rank == 0 and world == 1 and args.cert_seconds > 0:
+        # wall-clock to certificate on a fresh solve (setup + ADMM to eps_rel = 1e-6 or the time cap)
+        o2 = na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=200000, max_time=args.cert_seconds, eps_rel=1e-6)
+        t1 = time.perf_counter()
+        s2 = na.runQuery(q, o2)
+        out["time_to_cert"] = {"wall_s": time.perf_counter() - t1, "setup_s": s2.setup_time, "solve_s": s2.solve_time,
+                               "status": s2.termination_status, "iters": s2.summary["iters"], "rho": s2.objective_value,
+                               "pres": s2.summary["pres"], "dres": s2.summary["dres"], "lambda_max": s2.summary["lambda_max"],
+                               "eps": "pres,dres <= 1e-6 relative; lambda_max = eigmax(Z(gamma)) in the reference's coordinates"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

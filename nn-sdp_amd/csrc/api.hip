@@ -175,7 +175,7 @@ struct nnsdp_solver {
   int graph_iters = 0;
   std::vector<hipEvent_t> ev;
   std::unique_ptr<RocHandle> roc;
-  long long iters_done = 0;
+  long long iters_done = 0, next_adapt = 0;
   int since_cold = 0;
   double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
   double last_pres = 1e300, last_dres = 1e300, last_pobj = 0, last_dobj = 0;
@@ -301,14 +301,11 @@ struct nnsdp_solver {
     sigma = opt.sigma;
     double sc[2] = {sigma, 1.0};
     HIPCHK(hipMemcpy(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice));
-    if (lds_bytes > 64 * 1024) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    if (lds_bytes > 64 * 1024) HIPCHK(proj_allow_big_lds());
     t_setup = now_s() - t_create0;
   }
 
-  void launch_proj(bool warm) {
+  void enqueue_proj(bool warm) {
     ProjArgs a;
     a.cn = d_cn.p; a.coff = d_coff.p; a.eoff = nullptr;
     a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr;
@@ -316,15 +313,14 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = 1e-13;
-    if (v_lds) hipLaunchKernelGGL(k_proj_jacobi<true>, dim3(ncl), dim3(kThreads), lds_bytes, st, a);
-    else hipLaunchKernelGGL(k_proj_jacobi<false>, dim3(ncl), dim3(kThreads), lds_bytes, st, a);
+    nnsdp::launch_proj(a, ncl, nmax, v_lds, lds_bytes, st);
   }
 
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
   void enqueue_iteration(bool check, bool warm, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     int ng = S.ng, NE = S.NE;
     if (e0) HIPCHK(hipEventRecord(e0, st));
-    launch_proj(warm);
+    enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
     hipLaunchKernelGGL(k_gather_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
                        nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p);
@@ -422,6 +418,7 @@ struct nnsdp_solver {
     double t0 = now_s();
     int status = NNSDP_STATUS_ITERATION_LIMIT;
     int ce = opt.check_every;
+    if (next_adapt == 0) next_adapt = opt.adapt_every;
     while (iters_done < opt.max_iters) {
       int n = (int)std::min<long long>(ce - 1, opt.max_iters - iters_done - 1);
       iterate(n, nullptr);
@@ -432,9 +429,11 @@ struct nnsdp_solver {
       if (!(last_pres == last_pres) || !(last_dres == last_dres)) { status = NNSDP_STATUS_NUMERICAL_ERROR; break; }
       if (last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
       if (opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
-      if (opt.adapt_every > 0 && (iters_done / ce) % std::max(1, opt.adapt_every / ce) == 0) {
+      // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
+      if (opt.adapt_every > 0 && iters_done >= next_adapt) {
+        next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, iters_done * 3 / 2);
         double ratio = std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
-        if (ratio > 2.0 || ratio < 0.5) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
+        if (ratio > 1.5 || ratio < 0.67) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
       }
     }
     t_solve += now_s() - t0;
@@ -731,18 +730,14 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   bool v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
   size_t lds = proj_lds_bytes(nmax, v_lds);
-  if (lds > 64 * 1024) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
   a.kappa = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-15;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
-  if (v_lds) hipLaunchKernelGGL(k_proj_jacobi<true>, dim3(batch), dim3(kThreads), lds, nullptr, a);
-  else hipLaunchKernelGGL(k_proj_jacobi<false>, dim3(batch), dim3(kThreads), lds, nullptr, a);
+  launch_proj(a, batch, nmax, v_lds, lds, nullptr);
   HIPCHK(hipEventRecord(e1, nullptr));
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());

@@ -25,7 +25,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// block-wide sum, result valid in every thread; scratch >= 4 doubles of LDS
+// block-wide sum, result valid in every thread; scratch >= blockDim/64 doubles of LDS
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -62,9 +62,30 @@ struct ProjArgs {
   double tol;             // relative off-diagonal tolerance
 };
 
-template <bool V_LDS>
-__global__ __launch_bounds__(kThreads) void k_proj_jacobi(ProjArgs a) {
+// element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
+__device__ __forceinline__ int sym_at(int i, int j, int lda) { return i >= j ? i * lda + j : j * lda + i; }
+
+// rotation (c, s) that annihilates a_pq:  J = [c s; -s c],  A <- J' A J
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
+  c = 1.0; s = 0.0;
+  if (apq != 0.0) {
+    double tau = (aqq - app) / (2.0 * apq);
+    double t = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
+    if (tau < 0.0) t = -t;
+    c = 1.0 / sqrt(1.0 + t * t);
+    s = t * c;
+  }
+}
+
+// NT = 1024 (16 waves hide the LDS latency of the rotation passes) for large blocks, 256 for small.
+// The LAST wave of the workgroup computes the next round's rotation parameters while the other
+// waves apply the current round's rotations to the eigenvectors.
+template <bool V_LDS, int NT>
+__global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   extern __shared__ double lds[];
+  constexpr int TB = (NT == 1024) ? 32 : 16;   // block-update mapping: TA x TB threads
+  constexpr int TA = NT / TB;
+  constexpr int VP = (NT - 64) / 32;           // pair-slots processed at once by the V update
   const int k = blockIdx.x;
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // even
@@ -72,192 +93,264 @@ __global__ __launch_bounds__(kThreads) void k_proj_jacobi(ProjArgs a) {
   const int lda = np + 1;        // odd stride (in doubles): column walks hit distinct banks
   const int tid = threadIdx.x;
   double* A = lds;
-  double* cs = A + (size_t)np * lda;  // 2 * half rotation parameters
-  double* red = cs + np;              // 8 doubles of reduction scratch
+  double* cs = A + (size_t)np * lda;            // 2 buffers x (c, s) of each pair slot
+  double* red = cs + 2 * np;                    // 16 doubles of reduction scratch
+  int* slot = reinterpret_cast<int*>(red + 16); // 2 x np ints: [buf][0..half) top, [half..np) bottom
+  int* sel = slot + 2 * np;                     // np ints: eigen-indices on the chosen side
   double* V;
   int ldv;
-  if (V_LDS) { V = red + 8; ldv = np + 1; }
+  if (V_LDS) { V = red + 16 + np + (np >> 1) + 2; ldv = np + 1; }
   else { V = a.Vg + a.coff[k]; ldv = n; }
   const double* nuk = a.nu + a.coff[k];
 
-  // ---- load: A = sym(nu_k), padded row/col zero
+  // ---- load: A = sym(nu_k) (full, both triangles, for the warm-start products), padded row/col zero
   double fro2 = 0.0;
-  for (int idx = tid; idx < np * np; idx += kThreads) {
-    int i = idx % np, j = idx / np;
-    double v = 0.0;
-    if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
-    A[i * lda + j] = v;
-    fro2 += v * v;
-  }
+  for (int j = tid >> 6; j < np; j += NT >> 6)
+    for (int i = tid & 63; i < np; i += 64) {
+      double v = 0.0;
+      if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
+      A[i * lda + j] = v;
+      fro2 += v * v;
+    }
   fro2 = block_sum(fro2, red);
   // ---- starting basis
   const bool warm = a.warm != 0;
   if (V_LDS) {
-    for (int idx = tid; idx < np * np; idx += kThreads) {
-      int i = idx % np, j = idx / np;
-      double v = (i == j) ? 1.0 : 0.0;
-      if (warm && i < n && j < n) v = a.Vg[a.coff[k] + (size_t)j * n + i];
-      V[i + j * ldv] = v;
-    }
+    for (int j = tid >> 6; j < np; j += NT >> 6)
+      for (int i = tid & 63; i < np; i += 64) {
+        double v = (i == j) ? 1.0 : 0.0;
+        if (warm && i < n && j < n) v = a.Vg[a.coff[k] + (size_t)j * n + i];
+        V[i + j * ldv] = v;
+      }
   } else if (!warm) {
-    for (int idx = tid; idx < n * n; idx += kThreads) {
-      int i = idx % n, j = idx / n;
-      V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
-    }
+    for (int j = tid >> 6; j < n; j += NT >> 6)
+      for (int i = tid & 63; i < n; i += 64) V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
   }
+  if (tid < np) slot[tid] = tid;   // top[i] = i, bottom[i] = half + i
   __syncthreads();
   const int nv = V_LDS ? np : n;  // rows/cols of V that exist
   if (warm) {
-    // A <- V' A V in two passes through registers (A is overwritten by T = A V, then by V' T).
-    // Static trip counts keep acc[] in VGPRs (a runtime-indexed array would go to scratch).
-    constexpr int kMaxOwn = (130 * 130 + kThreads - 1) / kThreads;
-    double acc[kMaxOwn];
-    const int tot = np * np;
+    // A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
+    //   T = A V   (written over A),   A' = V' T   (written over T)
+    constexpr int kTilesMax = 2048 / NT;               // (128/4) * (128/2) tiles at most
+    const int ti_n = (np + 3) >> 2, tj_n = np >> 1;    // tile grid
+    double acc[kTilesMax][8];
 #pragma unroll
-    for (int m = 0; m < kMaxOwn; ++m) {
-      int idx = tid + m * kThreads;
-      double s = 0.0;
-      if (idx < tot) {
-        int i = idx % np, j = idx / np;
-        if (j < nv)
-          for (int l = 0; l < nv; ++l) s += A[i * lda + l] * V[l + (size_t)j * ldv];
-        else
-          s = A[i * lda + j];
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int m = 0; m < kTilesMax; ++m) {
+        int t = tid + m * NT;
+        int tj = t / ti_n, ti = t - tj * ti_n;         // consecutive threads -> consecutive row tiles
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        if (tj < tj_n) {
+          int i0 = ti * 4, j0 = tj * 2;
+          int i1 = min(i0 + 1, np - 1), i2 = min(i0 + 2, np - 1), i3 = min(i0 + 3, np - 1);
+          if (pass == 0) {
+            // T[i][j] = sum_l A[i][l] V[l][j]
+            const double* v0 = V + (size_t)min(j0, nv - 1) * ldv;
+            const double* v1 = V + (size_t)min(j0 + 1, nv - 1) * ldv;
+            const double *a0 = A + i0 * lda, *a1 = A + i1 * lda, *a2 = A + i2 * lda, *a3 = A + i3 * lda;
+            for (int l = 0; l < nv; ++l) {
+              double x0 = v0[l], x1 = v1[l];
+              double y0 = a0[l], y1 = a1[l], y2 = a2[l], y3 = a3[l];
+              c0 += y0 * x0; c1 += y1 * x0; c2 += y2 * x0; c3 += y3 * x0;
+              d0 += y0 * x1; d1 += y1 * x1; d2 += y2 * x1; d3 += y3 * x1;
+            }
+            if (j0 >= nv) { c0 = a0[j0]; c1 = a1[j0]; c2 = a2[j0]; c3 = a3[j0]; }
+            if (j0 + 1 >= nv) { d0 = a0[j0 + 1]; d1 = a1[j0 + 1]; d2 = a2[j0 + 1]; d3 = a3[j0 + 1]; }
+          } else {
+            // A'[i][j] = sum_l V[l][i] T[l][j]
+            const double *u0 = V + (size_t)min(i0, nv - 1) * ldv, *u1 = V + (size_t)min(i1, nv - 1) * ldv;
+            const double *u2 = V + (size_t)min(i2, nv - 1) * ldv, *u3 = V + (size_t)min(i3, nv - 1) * ldv;
+            for (int l = 0; l < nv; ++l) {
+              double x0 = A[l * lda + j0], x1 = A[l * lda + j0 + 1];
+              double y0 = u0[l], y1 = u1[l], y2 = u2[l], y3 = u3[l];
+              c0 += y0 * x0; c1 += y1 * x0; c2 += y2 * x0; c3 += y3 * x0;
+              d0 += y0 * x1; d1 += y1 * x1; d2 += y2 * x1; d3 += y3 * x1;
+            }
+            if (i0 >= nv) { c0 = A[i0 * lda + j0]; d0 = A[i0 * lda + j0 + 1]; }
+            if (i1 >= nv) { c1 = A[i1 * lda + j0]; d1 = A[i1 * lda + j0 + 1]; }
+            if (i2 >= nv) { c2 = A[i2 * lda + j0]; d2 = A[i2 * lda + j0 + 1]; }
+            if (i3 >= nv) { c3 = A[i3 * lda + j0]; d3 = A[i3 * lda + j0 + 1]; }
+          }
+        }
+        acc[m][0] = c0; acc[m][1] = c1; acc[m][2] = c2; acc[m][3] = c3;
+        acc[m][4] = d0; acc[m][5] = d1; acc[m][6] = d2; acc[m][7] = d3;
       }
-      acc[m] = s;
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll
-    for (int m = 0; m < kMaxOwn; ++m) {
-      int idx = tid + m * kThreads;
-      if (idx < tot) A[(idx % np) * lda + idx / np] = acc[m];
-    }
-    __syncthreads();
+      for (int m = 0; m < kTilesMax; ++m) {
+        int t = tid + m * NT;
+        int tj = t / ti_n, ti = t - tj * ti_n;
+        if (tj < tj_n) {
+          int i0 = ti * 4, j0 = tj * 2;
 #pragma unroll
-    for (int m = 0; m < kMaxOwn; ++m) {
-      int idx = tid + m * kThreads;
-      double s = 0.0;
-      if (idx < tot) {
-        int i = idx % np, j = idx / np;
-        if (i < nv)
-          for (int l = 0; l < nv; ++l) s += V[l + (size_t)i * ldv] * A[l * lda + j];
-        else
-          s = A[i * lda + j];
+          for (int r = 0; r < 4; ++r)
+            if (i0 + r < np) { A[(i0 + r) * lda + j0] = acc[m][r]; A[(i0 + r) * lda + j0 + 1] = acc[m][4 + r]; }
+        }
       }
-      acc[m] = s;
+      __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < kMaxOwn; ++m) {
-      int idx = tid + m * kThreads;
-      if (idx < tot) A[(idx % np) * lda + idx / np] = acc[m];
-    }
-    __syncthreads();
-    // enforce exact symmetry (the two passes round differently)
-    for (int idx = tid; idx < tot; idx += kThreads) {
-      int i = idx % np, j = idx / np;
-      if (i > j) A[i * lda + j] = 0.5 * (A[i * lda + j] + A[j * lda + i]);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < tot; idx += kThreads) {
-      int i = idx % np, j = idx / np;
-      if (i < j) A[i * lda + j] = A[j * lda + i];
-    }
+    // exact symmetry into the lower triangle (the two passes round differently)
+    for (int j = tid >> 6; j < np; j += NT >> 6)
+      for (int i = tid & 63; i < np; i += 64)
+        if (i > j) A[i * lda + j] = 0.5 * (A[i * lda + j] + A[j * lda + i]);
     __syncthreads();
   }
 
-  // ---- Jacobi sweeps
+  // ---- Jacobi sweeps (only the lower triangle of A is read and written from here on)
   const double thresh2 = a.tol * fro2;  // stop after a sweep that STARTED below sqrt(tol): it ends near tol (quadratic)
+  const int ta = tid / TB, tb = tid % TB;
+  const int vr = tid & 31, vp = tid >> 5;       // 32 rows x VP pair-slots for the eigenvector update
+  const int plane = tid - (NT - 64);            // lane index inside the parameter wave (>= 0 there)
+  double off2 = 0.0, off2_next = 0.0;
+  // prologue: parameters of round 0
+  if (plane >= 0 && plane < half) {
+    int p = slot[plane], q = slot[half + plane];
+    double apq = A[sym_at(p, q, lda)], c, s;
+    jacobi_cs(A[p * lda + p], A[q * lda + q], apq, c, s);
+    off2 += 2.0 * apq * apq;
+    cs[2 * plane] = c; cs[2 * plane + 1] = s;
+  }
+  __syncthreads();
   int sweeps = 0;
+  int buf = 0;
   for (; sweeps < a.max_sweeps; ++sweeps) {
-    double off2 = 0.0;
     for (int r = 0; r < np - 1; ++r) {
-      // (a) rotation parameters of this round's pairs
-      if (tid < half) {
-        int p, q;
-        if (tid == 0) { p = np - 1; q = r; }
-        else { p = (r + tid) % (np - 1); q = (r + np - 1 - tid) % (np - 1); }
-        double app = A[p * lda + p], aqq = A[q * lda + q], apq = A[p * lda + q];
-        double c = 1.0, s = 0.0;
-        off2 += 2.0 * apq * apq;
-        if (apq != 0.0) {
-          double tau = (aqq - app) / (2.0 * apq);
-          double t = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
-          if (tau < 0.0) t = -t;
-          c = 1.0 / sqrt(1.0 + t * t);
-          s = t * c;
+      const int* sl = slot + buf * np;
+      const double* csc = cs + buf * np;
+      // phase 1: A <- J' A J by 2x2 blocks on the lower block triangle; rows ia and half-1-ia are
+      // paired so every thread sees the same number of blocks.  Lanes 64.. rotate the slot table.
+      if (tid >= 64 && tid < 64 + np) {
+        // round robin: top[0] fixed; top[1] <- bottom[0]; top[i] <- top[i-1]; bottom[i] <- bottom[i+1];
+        // bottom[half-1] <- top[half-1]
+        int sidx = tid - 64;
+        int v;
+        if (sidx < half) v = (sidx == 0) ? sl[0] : (sidx == 1 ? sl[half] : sl[sidx - 1]);
+        else { int b = sidx - half; v = (b == half - 1) ? sl[half - 1] : sl[half + b + 1]; }
+        if (half == 1) v = sl[sidx];
+        slot[(buf ^ 1) * np + sidx] = v;
+      }
+      for (int ialo = ta; 2 * ialo < half; ialo += TA) {
+        int iahi = half - 1 - ialo;
+        int L = (ialo + 1) + (iahi != ialo ? iahi + 1 : 0);
+        for (int m = tb; m < L; m += TB) {
+          int ia, ib;
+          if (m <= ialo) { ia = ialo; ib = m; } else { ia = iahi; ib = m - ialo - 1; }
+          int p1 = sl[ia], q1 = sl[half + ia], p2 = sl[ib], q2 = sl[half + ib];
+          double c1 = csc[2 * ia], s1 = csc[2 * ia + 1], c2 = csc[2 * ib], s2 = csc[2 * ib + 1];
+          int e00 = sym_at(p1, p2, lda), e01 = sym_at(p1, q2, lda), e10 = sym_at(q1, p2, lda), e11 = sym_at(q1, q2, lda);
+          double b00 = A[e00], b01 = A[e01], b10 = A[e10], b11 = A[e11];
+          double t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
+          double t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
+          b00 = t00 * c2 - t01 * s2;
+          b01 = t00 * s2 + t01 * c2;
+          b10 = t10 * c2 - t11 * s2;
+          b11 = t10 * s2 + t11 * c2;
+          if (ia == ib) { A[e00] = b00; A[e11] = b11; A[e01] = 0.0; }
+          else { A[e00] = b00; A[e01] = b01; A[e10] = b10; A[e11] = b11; }
         }
-        cs[2 * tid] = c;
-        cs[2 * tid + 1] = s;
       }
       __syncthreads();
-      // (b) A <- J' A J by 2x2 blocks; block (ia, ib) = rows {p,q}(ia) x cols {p,q}(ib)
-      for (int blk = tid; blk < half * half; blk += kThreads) {
-        int ia = blk / half, ib = blk % half;
-        int p1, q1, p2, q2;
-        if (ia == 0) { p1 = np - 1; q1 = r; } else { p1 = (r + ia) % (np - 1); q1 = (r + np - 1 - ia) % (np - 1); }
-        if (ib == 0) { p2 = np - 1; q2 = r; } else { p2 = (r + ib) % (np - 1); q2 = (r + np - 1 - ib) % (np - 1); }
-        double c1 = cs[2 * ia], s1 = cs[2 * ia + 1], c2 = cs[2 * ib], s2 = cs[2 * ib + 1];
-        double b00 = A[p1 * lda + p2], b01 = A[p1 * lda + q2], b10 = A[q1 * lda + p2], b11 = A[q1 * lda + q2];
-        double t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
-        double t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
-        b00 = t00 * c2 - t01 * s2;
-        b01 = t00 * s2 + t01 * c2;
-        b10 = t10 * c2 - t11 * s2;
-        b11 = t10 * s2 + t11 * c2;
-        if (ia == ib) { b01 = 0.0; b10 = 0.0; }
-        A[p1 * lda + p2] = b00; A[p1 * lda + q2] = b01; A[q1 * lda + p2] = b10; A[q1 * lda + q2] = b11;
-      }
-      // (c) V <- V J by (row, pair) items
-      for (int it = tid; it < nv * half; it += kThreads) {
-        int row = it % nv, ia = it / nv;
-        int p, q;
-        if (ia == 0) { p = np - 1; q = r; } else { p = (r + ia) % (np - 1); q = (r + np - 1 - ia) % (np - 1); }
-        if (p >= nv || q >= nv) continue;  // padded index: rotation is the identity
-        double c = cs[2 * ia], s = cs[2 * ia + 1];
-        double vp = V[row + (size_t)p * ldv], vq = V[row + (size_t)q * ldv];
-        V[row + (size_t)p * ldv] = c * vp - s * vq;
-        V[row + (size_t)q * ldv] = s * vp + c * vq;
+      // phase 2: V <- V J (all waves but the last)  ||  next round's parameters (last wave)
+      if (plane >= 0) {
+        if (plane < half) {
+          const int* sn = slot + (buf ^ 1) * np;
+          int p = sn[plane], q = sn[half + plane];
+          double apq = A[sym_at(p, q, lda)], c, s;
+          jacobi_cs(A[p * lda + p], A[q * lda + q], apq, c, s);
+          if (r + 1 < np - 1) off2 += 2.0 * apq * apq; else off2_next += 2.0 * apq * apq;
+          cs[(buf ^ 1) * np + 2 * plane] = c;
+          cs[(buf ^ 1) * np + 2 * plane + 1] = s;
+        }
+      } else {
+        for (int ia = vp; ia < half; ia += VP) {
+          int p = sl[ia], q = sl[half + ia];
+          if (!V_LDS && (p >= nv || q >= nv)) continue;  // padded index: rotation is the identity
+          double c = csc[2 * ia], s = csc[2 * ia + 1];
+          double* colp = V + (size_t)p * ldv;
+          double* colq = V + (size_t)q * ldv;
+          for (int row = vr; row < nv; row += 32) {
+            double xp = colp[row], xq = colq[row];
+            colp[row] = c * xp - s * xq;
+            colq[row] = s * xp + c * xq;
+          }
+        }
       }
       __syncthreads();
+      buf ^= 1;
     }
-    off2 = block_sum(off2, red);
-    if (off2 <= thresh2) { ++sweeps; break; }
+    double tot_off = block_sum(off2, red);
+    off2 = off2_next;
+    off2_next = 0.0;
+    if (tot_off <= thresh2) { ++sweeps; break; }
   }
   if (tid == 0 && a.stats) { atomicAdd(&a.stats[0], sweeps); atomicMax(&a.stats[1], sweeps); }
 
-  // ---- eigenvalues on the diagonal; pick the smaller side of the spectrum for the rank-k update
-  int npos = 0, nneg = 0;
-  for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; npos += (l > 0.0); nneg += (l < 0.0); }
-  const bool use_pos = npos <= nneg;
+  // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
+  if (tid == 0) {
+    int npos = 0, nneg = 0;
+    for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; npos += (l > 0.0); nneg += (l < 0.0); }
+    bool use_pos = npos <= nneg;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; if (use_pos ? (l > 0.0) : (l < 0.0)) sel[cnt++] = i; }
+    slot[0] = cnt;
+    slot[1] = use_pos ? 1 : 0;
+  }
+  __syncthreads();
+  const int nsel = slot[0];
+  const bool use_pos = slot[1] != 0;
   if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[tid * lda + tid];
   const double kap = a.kappa ? *a.kappa : 1.0;
   double* wk = a.w + a.coff[k];
   double* nuw = a.nu + a.coff[k];
-  for (int idx = tid; idx < n * n; idx += kThreads) {
-    int i = idx % n, j = idx / n;
-    double s = 0.0;
-    if (use_pos) {
-      for (int l = 0; l < n; ++l) { double lam = A[l * lda + l]; if (lam > 0.0) s += lam * V[i + (size_t)l * ldv] * V[j + (size_t)l * ldv]; }
-    } else {
-      for (int l = 0; l < n; ++l) { double lam = A[l * lda + l]; if (lam < 0.0) s += lam * V[i + (size_t)l * ldv] * V[j + (size_t)l * ldv]; }
-      s = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]) - s;
+  for (int j = tid >> 6; j < n; j += NT >> 6)
+    for (int i = tid & 63; i < n; i += 64) {
+      double s = 0.0;
+      for (int t = 0; t < nsel; ++t) {
+        int l = sel[t];
+        s += A[l * lda + l] * V[i + (size_t)l * ldv] * V[j + (size_t)l * ldv];
+      }
+      double nij = nuk[(size_t)j * n + i], nji = nuk[(size_t)i * n + j];
+      if (!use_pos) s = 0.5 * (nij + nji) - s;
+      wk[(size_t)j * n + i] = s;
     }
-    wk[idx] = s;
-  }
   if (kap != 1.0) {
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += kThreads) { double wv = wk[idx]; nuw[idx] = wv + kap * (nuw[idx] - wv); }
+    for (int idx = tid; idx < n * n; idx += NT) { double wv = wk[idx]; nuw[idx] = wv + kap * (nuw[idx] - wv); }
   }
   if (V_LDS) {
     double* vg = a.Vg + a.coff[k];
-    for (int idx = tid; idx < n * n; idx += kThreads) vg[idx] = V[(idx % n) + (idx / n) * ldv];
+    for (int j = tid >> 6; j < n; j += NT >> 6)
+      for (int i = tid & 63; i < n; i += 64) vg[(size_t)j * n + i] = V[i + j * ldv];
   }
+}
+
+// launch: NT = 1024 for blocks above kSmallBlock, 256 below
+static constexpr int kSmallBlock = 40;
+inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st) {
+  if (nmax > kSmallBlock) {
+    if (v_lds) hipLaunchKernelGGL((k_proj_jacobi<true, 1024>), dim3(nblocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_proj_jacobi<false, 1024>), dim3(nblocks), dim3(1024), lds, st, a);
+  } else {
+    if (v_lds) hipLaunchKernelGGL((k_proj_jacobi<true, 256>), dim3(nblocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_proj_jacobi<false, 256>), dim3(nblocks), dim3(256), lds, st, a);
+  }
+}
+inline hipError_t proj_allow_big_lds() {
+  hipError_t e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds) {
   int np = (nmax + 1) & ~1;
-  size_t d = (size_t)np * (np + 1) + np + 8;
+  size_t d = (size_t)np * (np + 1) + 2 * np + 16 + np + (np >> 1) + 2;   // A, cs[2], red, slot[2][np] + sel[np] (ints)
   if (v_lds) d += (size_t)np * (np + 1);
   return d * sizeof(double);
 }

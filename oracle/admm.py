@@ -35,7 +35,7 @@ from .operator import LmiOperator, SQRT2
 class AdmmOptions:
     max_iters: int = 20000
     eps_rel: float = 1e-6            # on both splitting residuals, relative
-    sigma: float = 1.0
+    sigma: float = 0.1
     alpha: float = 1.6               # over-relaxation
     adapt_sigma: bool = True
     adapt_every: int = 50
@@ -166,6 +166,7 @@ def admm_solve(L: LmiOperator, opts: Optional[AdmmOptions] = None) -> AdmmResult
     rp = rd = np.inf
     it = 0
     x = None
+    next_adapt = opts.adapt_every
     for it in range(1, opts.max_iters + 1):
         nu_prev = S.nu
         w, x, res, Kxq = S.step()
@@ -182,9 +183,11 @@ def admm_solve(L: LmiOperator, opts: Optional[AdmmOptions] = None) -> AdmmResult
             if rp <= opts.eps_rel and rd <= opts.eps_rel:
                 status = "OPTIMAL"
                 break
-            if opts.adapt_sigma and it % opts.adapt_every == 0:
+            # residual balancing on a geometric schedule (a fixed period makes sigma oscillate)
+            if opts.adapt_sigma and it >= next_adapt:
+                next_adapt = max(it + 2 * opts.adapt_every, it * 3 // 2)
                 ratio = np.sqrt(max(rp, 1e-300) / max(rd, 1e-300))
-                if ratio > 2.0 or ratio < 0.5:
+                if ratio > 1.5 or ratio < 0.67:
                     S.set_sigma(S.sigma * min(max(ratio, 0.2), 5.0))
     w = S.proj(S.nu)
     y = S.sigma * (S.nu - w)

@@ -31,6 +31,6 @@ for name, beta in (("W10-D5", 0), ("W10-D10", 0), ("W10-D20", 0), ("W20-D10", 0)
     d = helpers.load_problem(name, beta)
     q = helpers.product_query(d)
     t = time.time()
-    s = na.runQuery(q, na.AdmmSdpOptions(max_iters=int(os.environ.get("ITERS", 6000)), verbose=False))
+    s = na.runQuery(q, na.AdmmSdpOptions(max_iters=int(os.environ.get("ITERS", 6000)), verbose=(name=="W20-D10")))
     print(name, beta, "rho", s.objective_value, s.termination_status, "iters", s.summary["iters"], "pres %.2e dres %.2e lmax %.2e" % (s.summary["pres"], s.summary["dres"], s.summary["lambda_max"]),
           "setup %.2f solve %.2f total %.2f wall %.2f" % (s.setup_time, s.solve_time, s.total_time, time.time() - t), "published", helpers.published_rho(name, beta))
