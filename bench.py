@@ -149,7 +149,7 @@ def main():
                          "kernel": "k_proj_jacobi", "kernel_avg_us": eig_avg_s * 1e6,
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
                          "hbm_achieved_GBs": byts / eig_avg_s / 1e9, "hbm_frac": byts / eig_avg_s / 1e9 / HBM_PEAK_GBS},
-            "eig_share_of_step": eig_avg_s / (dt / args.steps),
+            "eig_share_of_step": eig_avg_s / (dt / args.steps), "avg_jacobi_sweeps": sm["avg_sweeps"],
             "graph_replay_iters_per_s": graph_ips,
             "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
         }

@@ -105,6 +105,7 @@ typedef struct nnsdp_result {
   int32_t max_clique;     /* largest block dimension solved */
   int64_t eig_flops_per_iter; /* 10 * sum n_k^3 over the blocks solved */
   int64_t eig_bytes_per_iter; /* 2 * 8 * sum n_k^2 */
+  double avg_sweeps;      /* Jacobi sweeps per block per iteration, averaged over the solve */
 } nnsdp_result;
 
 int nnsdp_version(void);

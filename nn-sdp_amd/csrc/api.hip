@@ -312,7 +312,7 @@ struct nnsdp_solver {
     a.kappa = d_kappa(); a.stats = d_stats.p;
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
-    a.tol = 1e-13;
+    a.tol = kProjTol;
     nnsdp::launch_proj(a, ncl, nmax, v_lds, lds_bytes, st);
   }
 
@@ -343,6 +343,8 @@ struct nnsdp_solver {
   }
 
   // a cold eigendecomposition every kColdPeriod iterations bounds the drift of the warm basis
+  // a sweep that starts with relative off-diagonal norm <= sqrt(kProjTol) = 1e-5 ends near 1e-10
+  static constexpr double kProjTol = 1e-10;
   static constexpr int kColdPeriod = 64;
   static constexpr int kGraphIters = 8;
   bool next_is_warm() {
@@ -503,6 +505,10 @@ struct nnsdp_solver {
     for (int k = 0; k < ncl; ++k) { f += 10LL * cn[k] * cn[k] * cn[k]; b += 16LL * cn[k] * cn[k]; }
     r->eig_flops_per_iter = f;
     r->eig_bytes_per_iter = b;
+    {
+      std::vector<int> stv = d_stats.download();
+      r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
+    }
   }
 
   // a nnsdp_problem view over the deep copy (column-major M rebuilt)

@@ -50,7 +50,7 @@ class Result(C.Structure):
         ("pres", C.c_double), ("dres", C.c_double), ("lambda_max", C.c_double),
         ("t_setup", C.c_double), ("t_solve", C.c_double), ("t_total", C.c_double), ("t_eig", C.c_double),
         ("n_cliques", C.c_int32), ("max_clique", C.c_int32),
-        ("eig_flops_per_iter", C.c_int64), ("eig_bytes_per_iter", C.c_int64),
+        ("eig_flops_per_iter", C.c_int64), ("eig_bytes_per_iter", C.c_int64), ("avg_sweeps", C.c_double),
     ]
 
 

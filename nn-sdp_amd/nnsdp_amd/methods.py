@@ -312,7 +312,8 @@ def _solution(cp: _CProblem, r, bufs) -> QuerySolution:
         values["γout"] = bufs["gout"][:1]
     summary = dict(iters=r.iters, pres=r.pres, dres=r.dres, lambda_max=r.lambda_max, t_eig=r.t_eig,
                    n_cliques=r.n_cliques, max_clique=r.max_clique,
-                   eig_flops_per_iter=r.eig_flops_per_iter, eig_bytes_per_iter=r.eig_bytes_per_iter)
+                   eig_flops_per_iter=r.eig_flops_per_iter, eig_bytes_per_iter=r.eig_bytes_per_iter,
+                   avg_sweeps=r.avg_sweeps)
     return QuerySolution(objective_value=r.objective, values=values,
                          termination_status=lib.nnsdp_status_string(r.status).decode(),
                          total_time=r.t_total, setup_time=r.t_setup, solve_time=r.t_solve, summary=summary)

@@ -1,0 +1,256 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(nn-sdp_amd/nnsdp_amd -> libnnsdp_hip.so); the oracle is only the checker.
+
+Tolerances: fp64 throughout.  Assembly / adjoint: 1e-12 relative (different summation order only).
+PSD projection: 1e-10 * |A| (Jacobi vs LAPACK).  Solver: the HIP ADMM and the oracle ADMM run the
+same iteration, so objectives agree to 1e-6 relative after the same number of iterations; against the
+reference's published MOSEK objective the tolerance is 1e-3 relative."""
+import numpy as np
+import pytest
+
+import helpers
+import nnsdp_amd as na
+from oracle import admm as oadmm, operator as oop, qc
+
+pytestmark = pytest.mark.gpu
+
+
+def _sym(rng, n, scale=1.0):
+    A = rng.standard_normal((n, n)) * scale
+    return 0.5 * (A + A.T)
+
+
+def _ref_proj(A):
+    return oadmm.project_psd(A)
+
+
+# ----------------------------------------------------------------------------- K3: PSD projection
+def test_projection_matches_lapack_ragged_batch():
+    rng = np.random.default_rng(0)
+    mats = [_sym(rng, n) for n in (1, 2, 3, 5, 16, 23, 31, 40, 41, 64, 83, 85, 97, 98, 99, 121, 127, 128)]
+    res, evs, ms = na.project_psd_batched(mats)
+    assert ms > 0
+    for A, P, ev in zip(mats, res, evs):
+        nrm = max(1.0, np.abs(A).max())
+        assert np.abs(P - _ref_proj(A)).max() <= 1e-10 * nrm
+        assert np.abs(np.sort(ev) - np.linalg.eigvalsh(A)).max() <= 1e-10 * nrm
+        assert np.abs(P - P.T).max() <= 1e-12 * nrm
+
+
+def test_projection_edge_cases():
+    rng = np.random.default_rng(1)
+    n = 37
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    psd = (Q * np.linspace(0.1, 3, n)) @ Q.T
+    nsd = -psd
+    rank1 = np.outer(Q[:, 0], Q[:, 0]) * 2.5
+    repeated = (Q * np.repeat([2.0, -1.0, 0.0], [12, 12, 13])) @ Q.T
+    tiny = _sym(rng, n, 1e-150)
+    huge = _sym(rng, n, 1e120)
+    cases = [np.zeros((n, n)), np.eye(n), -np.eye(n), psd, nsd, rank1, repeated, np.diag(np.arange(n) - 18.0), tiny, huge,
+             np.array([[0.0]]), np.array([[-3.0]]), np.array([[0.0, 1.0], [1.0, 0.0]])]
+    res, _, _ = na.project_psd_batched(cases)
+    for A, P in zip(cases, res):
+        nrm = max(np.abs(A).max(), 1e-300)
+        assert np.all(np.isfinite(P))
+        assert np.abs(P - _ref_proj(A)).max() <= 1e-10 * nrm
+    assert np.array_equal(res[0], np.zeros((n, n)))
+    assert na.project_psd_batched([]) == ([], [], 0.0)        # empty batch
+    # a non-symmetric input is symmetrised, as LinearAlgebra.Symmetric does in the reference
+    B = rng.standard_normal((9, 9))
+    P, _, _ = na.project_psd_batched([B])
+    assert np.abs(P[0] - _ref_proj(0.5 * (B + B.T))).max() <= 1e-10
+
+
+def test_projection_properties_at_full_size():
+    """size-independent properties on a batch that fills the chip: 256 blocks of n = 121 (the nominal
+    W40 clique) and n = 85 (the largest block the normalised W40-D20 solve sees)."""
+    rng = np.random.default_rng(2)
+    for n in (121, 85):
+        mats = [_sym(rng, n) for _ in range(256)]
+        P, _, _ = na.project_psd_batched(mats)
+        Nn, _, _ = na.project_psd_batched([-A for A in mats])
+        PP, _, _ = na.project_psd_batched(P[:32])
+        for i, A in enumerate(mats):
+            assert np.abs(P[i] - Nn[i] - A).max() <= 1e-10           # Moreau: A = P(A) - P(-A)
+            assert abs(np.sum(P[i] * Nn[i])) <= 1e-8                 # complementary parts
+        for i in range(32):
+            assert np.abs(PP[i] - P[i]).max() <= 1e-10               # idempotence
+        assert np.linalg.eigvalsh(P[7]).min() >= -1e-10
+
+
+# ----------------------------------------------------------------------------- K1 / K2: assembly and adjoint
+@pytest.mark.parametrize("name,beta", [("W10-D5", 0), ("W10-D5", 3), ("W10-D10", 2)])
+def test_makeZ_and_adjoint_match_golden(name, beta):
+    d = helpers.load_problem(name, beta)
+    g = helpers.load_golden(name, beta)
+    q = helpers.product_query(d)
+    for gam, Z in zip(g["gammas"], g["Zs"]):
+        assert np.abs(na.makeZ(q, gam) - Z).max() <= 1e-12 * np.abs(Z).max()
+    for X, adj in zip(g["Xs"], g["adj"]):
+        assert np.abs(na.adjoint(q, X) - adj).max() <= 1e-11 * max(1.0, np.abs(adj).max())
+
+
+@pytest.mark.parametrize("out", ["hplane", "circle", "safety"])
+def test_makeZ_other_output_qcs(out):
+    d = helpers.load_problem("W10-D5", 3)
+    qo0 = helpers.oracle_query(d)
+    kw = {}
+    if out == "hplane":
+        kw["normal"] = [np.cos(0.7), np.sin(0.7)]
+    if out == "safety":
+        kw["S"] = qc.hplane_S([1.0, -2.0], 0.3, qo0.net) + 0.1 * np.eye(5)
+    q, qo = helpers.product_query(d, out=out, **kw), helpers.oracle_query(d, out=out, **kw)
+    gam = np.random.default_rng(4).random(qo.ngamma)
+    Z = qc.assemble_Z_literal(qo, gam)
+    assert np.abs(na.makeZ(q, gam) - Z).max() <= 1e-12 * np.abs(Z).max()
+
+
+def test_assembly_linearity_and_adjoint_identity_full_size():
+    """BASELINE sizes (W40-D20 beta=2, W40-D40 beta=0): affinity of gamma -> Z and <Z(g)-Z(0), X> = g'adj(X)."""
+    rng = np.random.default_rng(5)
+    for name, beta in (("W40-D20", 2), ("W40-D40", 0)):
+        d = helpers.load_problem(name, beta)
+        q = helpers.product_query(d)
+        ng = na.methods._CProblem(q).ngamma
+        g1, g2 = rng.random(ng), rng.random(ng)
+        Z0, Z1, Z2 = na.makeZ(q, np.zeros(ng)), na.makeZ(q, g1), na.makeZ(q, g2)
+        Z12 = na.makeZ(q, 0.3 * g1 + 1.7 * g2)
+        scale = np.abs(Z12).max()
+        assert np.abs((Z12 - Z0) - 0.3 * (Z1 - Z0) - 1.7 * (Z2 - Z0)).max() <= 1e-11 * scale
+        assert np.abs(Z1 - Z1.T).max() == 0.0
+        n = Z0.shape[0]
+        X = _sym(rng, n)
+        lhs = np.sum((Z1 - Z0) * X)
+        rhs = g1 @ na.adjoint(q, X)
+        assert abs(lhs - rhs) <= 1e-10 * max(1.0, abs(lhs))
+        # support inside the union of clique blocks (chordal_sdp.jl:150 makes everything else 0 == 0)
+        mask = np.zeros((n, n), dtype=bool)
+        for c in na.makeCliques(d["xdims"], beta, na.SingleDecomp):
+            mask[np.ix_(c, c)] = True
+        assert np.abs(Z1[~mask]).max() == 0.0
+
+
+def test_makeZ_matches_oracle_structured_w40_d20():
+    d = helpers.load_problem("W40-D20", 0)
+    q, qo = helpers.product_query(d), helpers.oracle_query(d)
+    L = oop.build_operator(qo, "single")
+    gam = np.random.default_rng(6).random(qo.ngamma)
+    Z = L.Z_dense(gam)
+    assert np.abs(na.makeZ(q, gam) - Z).max() <= 1e-12 * np.abs(Z).max()
+
+
+# ----------------------------------------------------------------------------- solver
+def _oracle_solve(d, mode, iters, **kw):
+    qo = helpers.oracle_query(d, **kw)
+    return oadmm.admm_solve(oop.build_operator(qo, mode, normalize=True), oadmm.AdmmOptions(max_iters=iters))
+
+
+@pytest.mark.parametrize("name,beta,iters", [("W10-D5", 0, 1500), ("W10-D5", 3, 800), ("W10-D10", 0, 1000)])
+def test_admm_tracks_oracle_iteration_for_iteration(name, beta, iters):
+    d = helpers.load_problem(name, beta)
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=iters))
+    r = _oracle_solve(d, "single", iters)
+    assert s.summary["iters"] == r.iters
+    assert s.termination_status == r.status
+    assert abs(s.objective_value - r.objective) <= 1e-6 * abs(r.objective) + 1e-12
+    assert abs(s.summary["pres"] - r.pres) <= 1e-3 * r.pres + 1e-9
+    assert abs(s.summary["dres"] - r.dres) <= 1e-3 * r.dres + 1e-9
+    gam = np.concatenate([s.values["γin"], s.values["γout"], s.values["γac1"], s.values["γac2"]])
+    assert gam.min() >= 0.0
+    # values[:Z] is Z(gamma) in the reference's coordinates (Methods.jl:86)
+    Zo = oop.build_operator(helpers.oracle_query(d), "dense").Z_dense(gam)
+    assert np.abs(s.values["Z"] - Zo).max() <= 1e-9 * max(1.0, np.abs(Zo).max())
+    assert abs(np.linalg.eigvalsh(s.values["Z"]).max() - s.summary["lambda_max"]) <= 1e-8 * max(1.0, np.abs(Zo).max())
+
+
+def test_decomposition_modes_agree():
+    d = helpers.load_problem("W10-D5", 0)
+    q = helpers.product_query(d)
+    rho = {}
+    for mode in (na.SingleDecomp(), na.DoubleDecomp(), na.DenseCone()):
+        s = na.runQuery(q, na.AdmmSdpOptions(max_iters=4000, decomp_mode=mode))
+        assert s.termination_status == "OPTIMAL"
+        rho[type(mode).__name__] = s.objective_value
+    # reference: the three methods agree to ~1e-4 relative on every OPTIMAL row
+    assert abs(rho["SingleDecomp"] - rho["DenseCone"]) <= 2e-4 * rho["DenseCone"]
+    assert abs(rho["DoubleDecomp"] - rho["DenseCone"]) <= 1e-3 * rho["DenseCone"]
+
+
+@pytest.mark.parametrize("out", ["hplane", "circle", "safety"])
+def test_other_queries_track_oracle(out):
+    d = helpers.load_problem("W10-D5", 0)
+    kw = {}
+    if out == "hplane":
+        kw["normal"] = [1.0, 0.0]
+    if out == "safety":
+        net = helpers.oracle_query(d).net
+        kw["S"] = qc.hplane_S([1.0, 0.0], 10.0, net)          # y_1 <= 10: comfortably safe
+    s = na.runQuery(helpers.product_query(d, out=out, **kw), na.AdmmSdpOptions(max_iters=600))
+    r = _oracle_solve(d, "single", 600, out=out, **kw)
+    assert abs(s.objective_value - r.objective) <= 1e-5 * abs(r.objective) + 1e-9
+    assert ("γout" in s.values) == (out != "safety")
+
+
+def test_unnormalised_solver_tracks_oracle():
+    """normalize=0 runs the ADMM in the reference's own coordinates (blocks up to the nominal clique size)."""
+    d = helpers.load_problem("W10-D5", 0)
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=300, normalize=False, sigma=1.0, adapt_every=0))
+    qo = helpers.oracle_query(d)
+    L = oop.build_operator(qo, "single", normalize=False)
+    P = oadmm.ScaledProblem.__new__(oadmm.ScaledProblem)
+    # unscaled problem: keep nonzero generators only, no column / objective scaling
+    import scipy.sparse as sp
+    A = L.A.tocsc()
+    cn = np.sqrt(np.asarray(A.multiply(A).sum(axis=0)).ravel())
+    P.keep = np.nonzero(cn > 1e-12)[0]
+    P.ecol = np.ones(len(P.keep)); P.A = A[:, P.keep]; P.c = L.c[P.keep]; P.z0 = L.z0
+    P.zscale = P.cscale = 1.0; P.pat = L.pat; P.ng_full = L.ng
+    S = oadmm.AdmmState(P, 1.0, 1.6)
+    for _ in range(300):
+        w, x, res, Kxq = S.step()
+    y = S.sigma * (S.nu - S.proj(S.nu))
+    rho = max(-y[list(P.keep).index(2)], 0.0)
+    assert abs(s.objective_value - rho) <= 1e-6 * abs(rho) + 1e-12
+    assert s.summary["max_clique"] == 31
+
+
+def test_published_objective_w10_d10():
+    """the reference's own golden values: dump/scale/*-scale-I2-O2-W10-D10.nnet.csv beta=0 (3 methods)."""
+    pub = helpers.published_rho("W10-D10", 0)
+    s = na.runQuery(helpers.product_query(helpers.load_problem("W10-D10", 0)), na.AdmmSdpOptions(max_iters=12000))
+    assert min(abs(s.objective_value - p) / p for p in pub) <= 1e-3, (s.objective_value, pub)
+    assert s.summary["pres"] <= 1e-5 and s.summary["dres"] <= 1e-5
+
+
+def test_full_size_solver_invariants_w40_d20():
+    """BASELINE configs[2] at full size: residuals decrease, gamma >= 0, Z symmetric and on the pattern."""
+    d = helpers.load_problem("W40-D20", 0)
+    sv = na.Solver(helpers.product_query(d), na.AdmmSdpOptions(max_iters=10 ** 8))
+    sv.iterate(200)
+    p1, d1, _, _ = sv.residuals()
+    sv.iterate(1500)
+    p2, d2, pobj, dobj = sv.residuals()
+    assert np.isfinite([p2, d2, pobj, dobj]).all()
+    assert p2 < p1 and max(p2, d2) < 0.5 * max(p1, d1)
+    s = sv.finish()
+    sv.close()
+    assert s.summary["n_cliques"] == 19 and s.summary["max_clique"] <= 121
+    gam = np.concatenate([s.values["γin"], s.values["γout"], s.values["γac1"], s.values["γac2"]])
+    assert gam.min() >= 0.0 and len(gam) == 3203
+    Z = s.values["Z"]
+    assert Z.shape == (803, 803) and np.abs(Z - Z.T).max() == 0.0
+
+
+def test_solver_argument_errors():
+    d = helpers.load_problem("W10-D5", 0)
+    q = helpers.product_query(d)
+    for bad in (dict(max_iters=0), dict(alpha=2.5), dict(sigma=-1.0), dict(decomp_mode=7)):
+        with pytest.raises(na._lib.NnsdpError) as ei:
+            na.runQuery(q, na.AdmmSdpOptions(**bad))
+        assert ei.value.code < 0
+    with pytest.raises(ValueError):
+        na.makeZ(q, np.zeros(5))
+    # Zdim 803 as ONE dense cone does not fit the LDS-resident kernel: refused, not silently slow
+    with pytest.raises(na._lib.NnsdpError):
+        na.runQuery(helpers.product_query(helpers.load_problem("W40-D20", 0)), na.AdmmSdpOptions(decomp_mode=na.DenseCone(), normalize=False, max_iters=10))
