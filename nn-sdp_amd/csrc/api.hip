@@ -343,8 +343,9 @@ struct nnsdp_solver {
   }
 
   // a cold eigendecomposition every kColdPeriod iterations bounds the drift of the warm basis
-  // a sweep that starts with relative off-diagonal norm <= sqrt(kProjTol) = 1e-5 ends near 1e-10
-  static constexpr double kProjTol = 1e-10;
+  // a sweep that starts with relative off-diagonal norm <= 1e-5 ends near 1e-10 (inexact projection
+  // well below the 1e-6 residual target; the certificate is checked independently at the end)
+  static constexpr double kProjTol = 1e-5;
   static constexpr int kColdPeriod = 64;
   static constexpr int kGraphIters = 8;
   bool next_is_warm() {
@@ -739,7 +740,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
-  a.kappa = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-15;
+  a.kappa = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));

@@ -59,7 +59,7 @@ struct ProjArgs {
   int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen
   int warm;               // 1: use Vg as the starting basis
   int max_sweeps;
-  double tol;             // relative off-diagonal tolerance
+  double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
 };
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   }
 
   // ---- Jacobi sweeps (only the lower triangle of A is read and written from here on)
-  const double thresh2 = a.tol * fro2;  // stop after a sweep that STARTED below sqrt(tol): it ends near tol (quadratic)
+  const double thresh2 = a.tol * a.tol * fro2;  // stop after a sweep that STARTED with off(A) <= tol |A|_F
   const int ta = tid / TB, tb = tid % TB;
   const int vr = tid & 31, vp = tid >> 5;       // 32 rows x VP pair-slots for the eigenvector update
   const int plane = tid - (NT - 64);            // lane index inside the parameter wave (>= 0 there)
