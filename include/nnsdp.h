@@ -76,6 +76,8 @@ typedef struct nnsdp_options {
   int32_t check_every;    /* convergence-check period, iterations (= iterations per hipGraph launch) */
   int32_t normalize;      /* 1: solver-internal interval congruence + fixed-neuron elimination (default) */
   int32_t warm_start;     /* 1: warm-start each eigendecomposition from the previous eigenvectors */
+  double proj_tol;        /* Jacobi stops at off(A) <= proj_tol |A|_F; 0 = adaptive: 0.01 x the current residual,
+                             clamped to [1e-9, 1e-4] (inexact projections well below the residual level) */
   int32_t verbose;        /* QueryOptions.verbose (src/Methods/Methods.jl:110) */
   int32_t device;         /* HIP device ordinal, -1 = current */
 } nnsdp_options;

@@ -168,7 +168,7 @@ struct nnsdp_solver {
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
   DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc, gs;
-  double sigma = 1.0;
+  double sigma = 1.0, proj_tol = 1e-4;
   hipStream_t st = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -291,7 +291,7 @@ struct nnsdp_solver {
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
     x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
-    scal.alloc(2); acc.alloc(8);
+    scal.alloc(4); acc.alloc(8);
     nu.zero(); w.zero(); Vg.zero(); x.zero(); g.zero(); qv.zero();
     {
       std::vector<double> s0(ng);
@@ -299,7 +299,8 @@ struct nnsdp_solver {
       HIPCHK(hipMemcpy(nu.p, s0.data(), ng * sizeof(double), hipMemcpyHostToDevice));
     }
     sigma = opt.sigma;
-    double sc[2] = {sigma, 1.0};
+    proj_tol = opt.proj_tol > 0 ? opt.proj_tol : 1e-4;
+    double sc[4] = {sigma, 1.0, proj_tol, 0.0};
     HIPCHK(hipMemcpy(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice));
     if (lds_bytes > 64 * 1024) HIPCHK(proj_allow_big_lds());
     t_setup = now_s() - t_create0;
@@ -309,7 +310,7 @@ struct nnsdp_solver {
     ProjArgs a;
     a.cn = d_cn.p; a.coff = d_coff.p; a.eoff = nullptr;
     a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr;
-    a.kappa = d_kappa(); a.stats = d_stats.p;
+    a.kappa = d_kappa(); a.tol_dev = scal.p + 2; a.stats = d_stats.p;
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
@@ -343,9 +344,9 @@ struct nnsdp_solver {
   }
 
   // a cold eigendecomposition every kColdPeriod iterations bounds the drift of the warm basis
-  // a sweep that starts with relative off-diagonal norm <= 1e-5 ends near 1e-10 (inexact projection
-  // well below the 1e-6 residual target; the certificate is checked independently at the end)
-  static constexpr double kProjTol = 1e-5;
+  // Jacobi stops when off(A) <= 1e-8 |A|_F (measured directly): an inexact projection two orders below
+  // the 1e-6 residual target; the certificate is checked independently at the end
+  static constexpr double kProjTol = 1e-8;   // (fixed-tolerance fallback; the default is adaptive, see update_proj_tol)
   static constexpr int kColdPeriod = 64;
   static constexpr int kGraphIters = 8;
   bool next_is_warm() {
@@ -410,6 +411,17 @@ struct nnsdp_solver {
     last_dobj = a[6] / (S.zscale * S.cscale);
   }
 
+  // inexact projections: Jacobi tolerance two orders below the current residual level
+  void update_proj_tol() {
+    if (opt.proj_tol > 0) return;
+    double t = std::min(1e-4, std::max(1e-9, 0.01 * std::max(last_pres, last_dres)));
+    if (t < 0.5 * proj_tol || t > 2.0 * proj_tol) {
+      proj_tol = t;
+      HIPCHK(hipMemcpyAsync(scal.p + 2, &proj_tol, sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+
   void set_sigma(double ns) {
     double sc[2] = {ns, sigma / ns};
     HIPCHK(hipMemcpyAsync(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice, st));
@@ -430,6 +442,7 @@ struct nnsdp_solver {
         std::fprintf(stderr, "[nnsdp] it %6lld pres %.3e dres %.3e obj %.8g dobj %.8g sigma %.3g\n", iters_done, last_pres,
                      last_dres, last_pobj, last_dobj, sigma);
       if (!(last_pres == last_pres) || !(last_dres == last_dres)) { status = NNSDP_STATUS_NUMERICAL_ERROR; break; }
+      update_proj_tol();
       if (last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
       if (opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
       // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
@@ -573,6 +586,7 @@ void nnsdp_default_options(nnsdp_options* o) {
   o->check_every = 50;
   o->normalize = 1;
   o->warm_start = 1;
+  o->proj_tol = 0.0;
   o->verbose = 0;
   o->device = -1;
 }
@@ -740,7 +754,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
-  a.kappa = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
+  a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));

@@ -56,6 +56,7 @@ struct ProjArgs {
   double* Vg;             // packed eigenvectors (in for warm start, out)
   double* eig;            // packed eigenvalues (out, may be null)
   const double* kappa;    // device scalar: nu <- w + kappa (nu - w) (penalty change), may be null
+  const double* tol_dev;  // device scalar overriding tol (lets the host adapt it between graph launches), may be null
   int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen
   int warm;               // 1: use Vg as the starting basis
   int max_sweeps;
@@ -65,17 +66,54 @@ struct ProjArgs {
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
 __device__ __forceinline__ int sym_at(int i, int j, int lda) { return i >= j ? i * lda + j : j * lda + i; }
 
-// rotation (c, s) that annihilates a_pq:  J = [c s; -s c],  A <- J' A J
+// 1/sqrt(x) to full fp64 accuracy from the hardware estimate (v_rsq_f64) + 3 Newton steps; avoids the
+// long software sqrt/divide sequences on the critical path of every Jacobi round
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
+// rotation (c, s) that annihilates a_pq:  J = [c s; -s c],  A <- J' A J.
+// With d = aqq - app, b = 2 apq, h = hypot(d, b):  cos(2 theta) = |d|/h,  c = sqrt((1 + |d|/h)/2),
+// s = sign(d) b / (2 h c)  (the small-angle root, |theta| <= pi/4).  Two rsqrt, no divide.
 __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
   c = 1.0; s = 0.0;
-  if (apq != 0.0) {
-    double tau = (aqq - app) / (2.0 * apq);
-    double t = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
-    if (tau < 0.0) t = -t;
-    c = 1.0 / sqrt(1.0 + t * t);
-    s = t * c;
+  double d = aqq - app, b = 2.0 * apq;
+  double h2 = d * d + b * b;
+  if (apq != 0.0 && h2 > 0.0 && h2 < 1e300) {
+    double rh = rsqrt_nr(h2);
+    double u = 0.5 + 0.5 * fabs(d) * rh;     // in [0.5, 1]
+    double rc = rsqrt_nr(u);
+    c = u * rc;
+    s = 0.5 * b * rh * rc;
+    if (d < 0.0) s = -s;
+    // one renormalisation makes c^2 + s^2 = 1 to rounding irrespective of the estimate accuracy
+    double nrm = rsqrt_nr(c * c + s * s);
+    c *= nrm; s *= nrm;
+  } else if (apq != 0.0) {
+    // extreme magnitudes (over/underflow of d^2 + b^2): scaled evaluation
+    double sc = fmax(fabs(d), fabs(b));
+    double dd = d / sc, bb = b / sc;
+    double rh = 1.0 / sqrt(dd * dd + bb * bb);
+    double u = 0.5 + 0.5 * fabs(dd) * rh;
+    c = sqrt(u);
+    s = 0.5 * bb * rh / c;
+    if (d < 0.0) s = -s;
   }
 }
+
+// round-robin (chess tournament) schedule in closed form: index 0 stays in top slot 0, the other
+// np-1 indices sit on a cycle  t1 -> t2 -> ... -> t(h-1) -> b(h-1) -> ... -> b0 -> t1  and advance one
+// position per round.  Pair slot ia holds (top, bottom) = (pair_top, pair_bot) at round r.
+__device__ __forceinline__ int cyc_content(int j, int r, int M, int half) {
+  int j0 = j - r;
+  if (j0 < 0) j0 += M;
+  return (j0 <= half - 2) ? j0 + 1 : 3 * half - 2 - j0;
+}
+__device__ __forceinline__ int pair_top(int ia, int r, int M, int half) { return ia == 0 ? 0 : cyc_content(ia - 1, r, M, half); }
+__device__ __forceinline__ int pair_bot(int ia, int r, int M, int half) { return cyc_content(2 * half - 2 - ia, r, M, half); }
 
 // NT = 1024 (16 waves hide the LDS latency of the rotation passes) for large blocks, 256 for small.
 // The LAST wave of the workgroup computes the next round's rotation parameters while the other
@@ -93,13 +131,12 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   const int lda = np + 1;        // odd stride (in doubles): column walks hit distinct banks
   const int tid = threadIdx.x;
   double* A = lds;
-  double* cs = A + (size_t)np * lda;            // 2 buffers x (c, s) of each pair slot
-  double* red = cs + 2 * np;                    // 16 doubles of reduction scratch
-  int* slot = reinterpret_cast<int*>(red + 16); // 2 x np ints: [buf][0..half) top, [half..np) bottom
-  int* sel = slot + 2 * np;                     // np ints: eigen-indices on the chosen side
+  double* desc = A + (size_t)np * lda;          // 2 buffers x half pair descriptors {c, s, (p, q)} = 3 doubles each
+  double* red = desc + 3 * np;                  // 16 doubles of reduction scratch
+  int* sel = reinterpret_cast<int*>(red + 16);  // np + 2 ints: eigen-indices on the chosen side, counters
   double* V;
   int ldv;
-  if (V_LDS) { V = red + 16 + np + (np >> 1) + 2; ldv = np + 1; }
+  if (V_LDS) { V = red + 16 + (np >> 1) + 2; ldv = np + 1; }
   else { V = a.Vg + a.coff[k]; ldv = n; }
   const double* nuk = a.nu + a.coff[k];
 
@@ -126,7 +163,6 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     for (int j = tid >> 6; j < n; j += NT >> 6)
       for (int i = tid & 63; i < n; i += 64) V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
   }
-  if (tid < np) slot[tid] = tid;   // top[i] = i, bottom[i] = half + i
   __syncthreads();
   const int nv = V_LDS ? np : n;  // rows/cols of V that exist
   if (warm) {
@@ -199,92 +235,154 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   }
 
   // ---- Jacobi sweeps (only the lower triangle of A is read and written from here on)
-  const double thresh2 = a.tol * a.tol * fro2;  // stop after a sweep that STARTED with off(A) <= tol |A|_F
-  const int ta = tid / TB, tb = tid % TB;
-  const int vr = tid & 31, vp = tid >> 5;       // 32 rows x VP pair-slots for the eigenvector update
+  const double tolv = a.tol_dev ? *a.tol_dev : a.tol;
+  const double thresh2 = tolv * tolv * fro2;  // converged when off(A) <= tol |A|_F, measured directly before each sweep
   const int plane = tid - (NT - 64);            // lane index inside the parameter wave (>= 0 there)
-  double off2 = 0.0, off2_next = 0.0;
-  // prologue: parameters of round 0
-  if (plane >= 0 && plane < half) {
-    int p = slot[plane], q = slot[half + plane];
-    double apq = A[sym_at(p, q, lda)], c, s;
-    jacobi_cs(A[p * lda + p], A[q * lda + q], apq, c, s);
-    off2 += 2.0 * apq * apq;
-    cs[2 * plane] = c; cs[2 * plane + 1] = s;
+  const int M = np - 1;                         // rounds per sweep
+  // static work assignment (round independent, so the integer divisions happen once):
+  //  * 2x2 blocks of the lower block triangle; block rows ia and half-1-ia are paired into rows of equal
+  //    length half+1 and the rectangle ceil(half/2) x (half+1) is dealt out thread by thread
+  //  * eigenvector units (pair slot, chunk of 32 rows) dealt out to 32-lane groups of all waves but the last
+  constexpr int MAXB = (NT == 1024) ? 3 : 9;
+  constexpr int MAXU = 9;
+  constexpr int VG = (NT - 64) / 32;
+  int blk[MAXB];
+  {
+    const int R = (half + 1) >> 1, Wd = half + 1;
+#pragma unroll
+    for (int u = 0; u < MAXB; ++u) {
+      int b = tid + u * NT;
+      int v = -1;
+      if (b < R * Wd) {
+        int row = b / Wd, m = b - row * Wd;
+        int iahi = half - 1 - row;
+        if (m <= row) v = (row << 8) | m;
+        else if (iahi != row) v = (iahi << 8) | (m - row - 1);
+      }
+      blk[u] = v;
+    }
   }
-  __syncthreads();
+  const int nch = (nv + 31) >> 5;
+  const int vr = tid & 31, vg = tid >> 5;
+  int vunit[MAXU];
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    int un = vg + u * VG;
+    int v = -1;
+    if (plane < 0 && un < half * nch) {
+      int ia = un / nch, ch = un - ia * nch;
+      int row = ch * 32 + vr;
+      if (row < nv) v = (ia << 8) | row;
+    }
+    vunit[u] = v;
+  }
+#ifdef NNSDP_STAMPS
+  long long st_acc[4] = {0, 0, 0, 0};
+#define STAMP(i, tprev) { long long tn_ = clock64(); st_acc[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define STAMP(i, tprev)
+#endif
   int sweeps = 0;
-  int buf = 0;
-  for (; sweeps < a.max_sweeps; ++sweeps) {
-    for (int r = 0; r < np - 1; ++r) {
-      const int* sl = slot + buf * np;
-      const double* csc = cs + buf * np;
-      // phase 1: A <- J' A J by 2x2 blocks on the lower block triangle; rows ia and half-1-ia are
-      // paired so every thread sees the same number of blocks.  Lanes 64.. rotate the slot table.
-      if (tid >= 64 && tid < 64 + np) {
-        // round robin: top[0] fixed; top[1] <- bottom[0]; top[i] <- top[i-1]; bottom[i] <- bottom[i+1];
-        // bottom[half-1] <- top[half-1]
-        int sidx = tid - 64;
-        int v;
-        if (sidx < half) v = (sidx == 0) ? sl[0] : (sidx == 1 ? sl[half] : sl[sidx - 1]);
-        else { int b = sidx - half; v = (b == half - 1) ? sl[half - 1] : sl[half + b + 1]; }
-        if (half == 1) v = sl[sidx];
-        slot[(buf ^ 1) * np + sidx] = v;
-      }
-      for (int ialo = ta; 2 * ialo < half; ialo += TA) {
-        int iahi = half - 1 - ialo;
-        int L = (ialo + 1) + (iahi != ialo ? iahi + 1 : 0);
-        for (int m = tb; m < L; m += TB) {
-          int ia, ib;
-          if (m <= ialo) { ia = ialo; ib = m; } else { ia = iahi; ib = m - ialo - 1; }
-          int p1 = sl[ia], q1 = sl[half + ia], p2 = sl[ib], q2 = sl[half + ib];
-          double c1 = csc[2 * ia], s1 = csc[2 * ia + 1], c2 = csc[2 * ib], s2 = csc[2 * ib + 1];
-          int e00 = sym_at(p1, p2, lda), e01 = sym_at(p1, q2, lda), e10 = sym_at(q1, p2, lda), e11 = sym_at(q1, q2, lda);
-          double b00 = A[e00], b01 = A[e01], b10 = A[e10], b11 = A[e11];
-          double t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
-          double t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
-          b00 = t00 * c2 - t01 * s2;
-          b01 = t00 * s2 + t01 * c2;
-          b10 = t10 * c2 - t11 * s2;
-          b11 = t10 * s2 + t11 * c2;
-          if (ia == ib) { A[e00] = b00; A[e11] = b11; A[e01] = 0.0; }
-          else { A[e00] = b00; A[e01] = b01; A[e10] = b10; A[e11] = b11; }
+  for (;;) {
+    // direct measurement of off(A)^2 (no cancellation): ~1/40 of a sweep
+    double off2 = 0.0;
+    for (int j = tid >> 6; j < np; j += NT >> 6)
+      for (int i = (tid & 63) + j + 1; i < np; i += 64) { double v = A[i * lda + j]; off2 += v * v; }
+    off2 = 2.0 * block_sum(off2, red);
+    if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
+    // parameters of round 0
+    if (plane >= 0 && plane < half) {
+      int p = pair_top(plane, 0, M, half), q = pair_bot(plane, 0, M, half);
+      double c, s;
+      jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], c, s);
+      double* dd = desc + 3 * plane;
+      dd[0] = c; dd[1] = s;
+      reinterpret_cast<int*>(dd + 2)[0] = p; reinterpret_cast<int*>(dd + 2)[1] = q;
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int r = 0; r < M; ++r) {
+#ifdef NNSDP_STAMPS
+      long long tprev = clock64();
+#endif
+      const double* dsc = desc + buf * 3 * half;
+      // phase 1: A <- J' A J on the lower block triangle
+      {
+        int e00[MAXB], e01[MAXB], e10[MAXB], e11[MAXB];
+        double b00[MAXB], b01[MAXB], b10[MAXB], b11[MAXB];
+        double2 r1[MAXB], r2[MAXB];
+#pragma unroll
+        for (int u = 0; u < MAXB; ++u) {
+          if (blk[u] >= 0) {
+            int ia = blk[u] >> 8, ib = blk[u] & 255;
+            const double* d1 = dsc + 3 * ia;
+            const double* d2 = dsc + 3 * ib;
+            r1[u] = make_double2(d1[0], d1[1]);
+            r2[u] = make_double2(d2[0], d2[1]);
+            int2 pq1 = *reinterpret_cast<const int2*>(d1 + 2), pq2 = *reinterpret_cast<const int2*>(d2 + 2);
+            e00[u] = sym_at(pq1.x, pq2.x, lda); e01[u] = sym_at(pq1.x, pq2.y, lda);
+            e10[u] = sym_at(pq1.y, pq2.x, lda); e11[u] = sym_at(pq1.y, pq2.y, lda);
+            b00[u] = A[e00[u]]; b01[u] = A[e01[u]]; b10[u] = A[e10[u]]; b11[u] = A[e11[u]];
+          }
         }
-      }
-      __syncthreads();
-      // phase 2: V <- V J (all waves but the last)  ||  next round's parameters (last wave)
-      if (plane >= 0) {
-        if (plane < half) {
-          const int* sn = slot + (buf ^ 1) * np;
-          int p = sn[plane], q = sn[half + plane];
-          double apq = A[sym_at(p, q, lda)], c, s;
-          jacobi_cs(A[p * lda + p], A[q * lda + q], apq, c, s);
-          if (r + 1 < np - 1) off2 += 2.0 * apq * apq; else off2_next += 2.0 * apq * apq;
-          cs[(buf ^ 1) * np + 2 * plane] = c;
-          cs[(buf ^ 1) * np + 2 * plane + 1] = s;
-        }
-      } else {
-        for (int ia = vp; ia < half; ia += VP) {
-          int p = sl[ia], q = sl[half + ia];
-          if (!V_LDS && (p >= nv || q >= nv)) continue;  // padded index: rotation is the identity
-          double c = csc[2 * ia], s = csc[2 * ia + 1];
-          double* colp = V + (size_t)p * ldv;
-          double* colq = V + (size_t)q * ldv;
-          for (int row = vr; row < nv; row += 32) {
-            double xp = colp[row], xq = colq[row];
-            colp[row] = c * xp - s * xq;
-            colq[row] = s * xp + c * xq;
+#pragma unroll
+        for (int u = 0; u < MAXB; ++u) {
+          if (blk[u] >= 0) {
+            double c1 = r1[u].x, s1 = r1[u].y, c2 = r2[u].x, s2 = r2[u].y;
+            double t00 = c1 * b00[u] - s1 * b10[u], t01 = c1 * b01[u] - s1 * b11[u];
+            double t10 = s1 * b00[u] + c1 * b10[u], t11 = s1 * b01[u] + c1 * b11[u];
+            double n00 = t00 * c2 - t01 * s2, n01 = t00 * s2 + t01 * c2;
+            double n10 = t10 * c2 - t11 * s2, n11 = t10 * s2 + t11 * c2;
+            if ((blk[u] >> 8) == (blk[u] & 255)) { A[e00[u]] = n00; A[e11[u]] = n11; A[e01[u]] = 0.0; }
+            else { A[e00[u]] = n00; A[e01[u]] = n01; A[e10[u]] = n10; A[e11[u]] = n11; }
           }
         }
       }
+      STAMP(0, tprev)
       __syncthreads();
+      STAMP(1, tprev)
+      // phase 2: V <- V J (all waves but the last)  ||  next round's parameters (last wave)
+      if (plane >= 0) {
+        if (plane < half && r + 1 < M) {
+          int p = pair_top(plane, r + 1, M, half), q = pair_bot(plane, r + 1, M, half);
+          double c, s;
+          jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], c, s);
+          double* dd = desc + (buf ^ 1) * 3 * half + 3 * plane;
+          dd[0] = c; dd[1] = s;
+          reinterpret_cast<int*>(dd + 2)[0] = p; reinterpret_cast<int*>(dd + 2)[1] = q;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+          if (vunit[u] >= 0) {
+            const double* d1 = dsc + 3 * (vunit[u] >> 8);
+            int row = vunit[u] & 255;
+            double c = d1[0], sn = d1[1];
+            int2 pq = *reinterpret_cast<const int2*>(d1 + 2);
+            if (V_LDS || (pq.x < nv && pq.y < nv)) {       // padded index: rotation is the identity
+              double* vp_ = V + (size_t)pq.x * ldv + row;
+              double* vq_ = V + (size_t)pq.y * ldv + row;
+              double xp = *vp_, xq = *vq_;
+              *vp_ = c * xp - sn * xq;
+              *vq_ = sn * xp + c * xq;
+            }
+          }
+        }
+      }
+      STAMP(2, tprev)
+      __syncthreads();
+      STAMP(3, tprev)
       buf ^= 1;
     }
-    double tot_off = block_sum(off2, red);
-    off2 = off2_next;
-    off2_next = 0.0;
-    if (tot_off <= thresh2) { ++sweeps; break; }
+    ++sweeps;
   }
+#ifdef NNSDP_STAMPS
+  if (k == 0 && (tid & 63) == 0 && a.eig) {   // debug build only: per-wave phase cycles into the tail of eig[]
+    long long* dbg = reinterpret_cast<long long*>(a.eig + 4096);
+    for (int i = 0; i < 4; ++i) dbg[(tid >> 6) * 4 + i] = st_acc[i];
+    if (tid == 0) dbg[64] = sweeps;
+  }
+#endif
   if (tid == 0 && a.stats) { atomicAdd(&a.stats[0], sweeps); atomicMax(&a.stats[1], sweeps); }
 
   // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
@@ -294,12 +392,12 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     bool use_pos = npos <= nneg;
     int cnt = 0;
     for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; if (use_pos ? (l > 0.0) : (l < 0.0)) sel[cnt++] = i; }
-    slot[0] = cnt;
-    slot[1] = use_pos ? 1 : 0;
+    sel[np] = cnt;
+    sel[np + 1] = use_pos ? 1 : 0;
   }
   __syncthreads();
-  const int nsel = slot[0];
-  const bool use_pos = slot[1] != 0;
+  const int nsel = sel[np];
+  const bool use_pos = sel[np + 1] != 0;
   if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[tid * lda + tid];
   const double kap = a.kappa ? *a.kappa : 1.0;
   double* wk = a.w + a.coff[k];
@@ -350,7 +448,7 @@ inline hipError_t proj_allow_big_lds() {
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds) {
   int np = (nmax + 1) & ~1;
-  size_t d = (size_t)np * (np + 1) + 2 * np + 16 + np + (np >> 1) + 2;   // A, cs[2], red, slot[2][np] + sel[np] (ints)
+  size_t d = (size_t)np * (np + 1) + 3 * np + 16 + (np >> 1) + 2;   // A, desc[2][half][3], red, sel[np+2] (ints)
   if (v_lds) d += (size_t)np * (np + 1);
   return d * sizeof(double);
 }

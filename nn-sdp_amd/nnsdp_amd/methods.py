@@ -183,6 +183,7 @@ class AdmmSdpOptions:
     check_every: int = 50
     normalize: bool = True
     warm_start: bool = True
+    proj_tol: float = 0.0          # 0 = adaptive (see include/nnsdp.h)
     verbose: bool = False
     device: int = -1
 
@@ -199,6 +200,7 @@ class AdmmSdpOptions:
         o.check_every = int(self.check_every)
         o.normalize = int(bool(self.normalize))
         o.warm_start = int(bool(self.warm_start))
+        o.proj_tol = float(self.proj_tol)
         o.verbose = int(bool(self.verbose))
         o.device = int(self.device)
         return o

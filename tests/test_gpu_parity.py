@@ -149,7 +149,7 @@ def _oracle_solve(d, mode, iters, **kw):
 @pytest.mark.parametrize("name,beta,iters", [("W10-D5", 0, 1500), ("W10-D5", 3, 800), ("W10-D10", 0, 1000)])
 def test_admm_tracks_oracle_iteration_for_iteration(name, beta, iters):
     d = helpers.load_problem(name, beta)
-    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=iters))
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=iters, proj_tol=1e-12))   # exact projections
     r = _oracle_solve(d, "single", iters)
     assert s.summary["iters"] == r.iters
     assert s.termination_status == r.status
@@ -198,7 +198,7 @@ def test_other_queries_track_oracle(out):
 def test_unnormalised_solver_tracks_oracle():
     """normalize=0 runs the ADMM in the reference's own coordinates (blocks up to the nominal clique size)."""
     d = helpers.load_problem("W10-D5", 0)
-    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=300, normalize=False, sigma=1.0, adapt_every=0))
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=300, normalize=False, sigma=1.0, adapt_every=0, proj_tol=1e-12))
     qo = helpers.oracle_query(d)
     L = oop.build_operator(qo, "single", normalize=False)
     P = oadmm.ScaledProblem.__new__(oadmm.ScaledProblem)
