@@ -1,0 +1,94 @@
+# Reference-side binding for libnnsdp_hip.so (include/nnsdp.h).  Drop this file into
+# src/Methods/ of AntonXue/nn-sdp and add `include("admm_sdp.jl"); export AdmmSdpOptions` after
+# the chordal_sdp.jl include in src/Methods/Methods.jl:141-143.  NOT executed in this repository
+# (no Julia in the build image); the ctypes mirror in nn-sdp_amd/nnsdp_amd binds the same symbols
+# and is what the tests exercise.
+#
+# Replaces, for opts::AdmmSdpOptions only, the generic runQuery (src/Methods/Methods.jl:91-131):
+# no JuMP model is built, no MOSEK is called.
+
+const LIBNNSDP = get(ENV, "NNSDP_LIB", "libnnsdp_hip.so")
+
+@with_kw struct AdmmSdpOptions <: QueryOptions
+  decomp_mode::DecompMode = SingleDecomp()   # SingleDecomp / DoubleDecomp (chordal_sdp.jl:4-8)
+  dense::Bool = false                        # true: one dense cone (DeepSdpOptions behaviour)
+  max_iters::Int = 20000
+  eps_rel::Float64 = 1e-6
+  max_time::Float64 = 0.0
+  sigma::Float64 = 0.1
+  alpha::Float64 = 1.6
+  adapt_every::Int = 50
+  check_every::Int = 50
+  normalize::Bool = true
+  warm_start::Bool = true
+  proj_tol::Float64 = 0.0
+  verbose::Bool = false
+  device::Int = -1
+end
+
+# field order and types must match include/nnsdp.h
+struct CProblem
+  K::Int32; xdims::Ptr{Int32}; M::Ptr{Float64}
+  x1min::Ptr{Float64}; x1max::Ptr{Float64}
+  acymin::Ptr{Float64}; acymax::Ptr{Float64}; smin::Ptr{Float64}; smax::Ptr{Float64}
+  beta::Int32; query_kind::Int32; out_kind::Int32
+  normal::Ptr{Float64}; yc::Ptr{Float64}; invP::Ptr{Float64}; S::Ptr{Float64}
+end
+struct COptions
+  decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
+  adapt_every::Int32; check_every::Int32; normalize::Int32; warm_start::Int32; proj_tol::Float64
+  verbose::Int32; device::Int32
+end
+mutable struct CResult
+  gamma_in::Ptr{Float64}; gamma_out::Ptr{Float64}; gamma_ac1::Ptr{Float64}; gamma_ac2::Ptr{Float64}; Z::Ptr{Float64}
+  objective::Float64; status::Int32; iters::Int32; pres::Float64; dres::Float64; lambda_max::Float64
+  t_setup::Float64; t_solve::Float64; t_total::Float64; t_eig::Float64
+  n_cliques::Int32; max_clique::Int32; eig_flops_per_iter::Int64; eig_bytes_per_iter::Int64; avg_sweeps::Float64
+end
+
+function runQuery(query::Query, opts::AdmmSdpOptions)
+  ffnet = query.ffnet
+  qb = only(filter(q -> q isa QcActivBounded, query.qc_activs))
+  qs = only(filter(q -> q isa QcActivSector, query.qc_activs))
+  xdims = Int32.(ffnet.xdims)
+  M = vcat([vec(Matrix{Float64}(Mk)) for Mk in ffnet.Ms]...)           # column-major, back to back
+  x1min, x1max = Float64.(query.qc_input.x1min), Float64.(query.qc_input.x1max)
+  acymin, acymax = Float64.(qb.acymin), Float64.(qb.acymax)
+  smin, smax = Float64.(Vector(qs.smin)), Float64.(Vector(qs.smax))
+  normal = Float64[]; yc = Float64[]; invP = Float64[]; S = Float64[]
+  if query isa ReachQuery
+    qkind = Int32(1); qo = query.qc_reach
+    if qo isa QcReachHplane;        okind = Int32(1); normal = Float64.(qo.normal)
+    elseif qo isa QcReachCircle;    okind = Int32(2); yc = Float64.(qo.yc)
+    elseif qo isa QcReachEllipsoid; okind = Int32(3); yc = Float64.(qo.yc); invP = vec(Matrix{Float64}(qo.invP))
+    else error("unrecognized qc: $(qo)") end
+  elseif query isa SafetyQuery
+    qkind = Int32(0); okind = Int32(0); S = vec(Matrix{Float64}(query.qc_safety.S))
+  else
+    error("unrecognized query: $(query)")
+  end
+  Zdim = sum(ffnet.zdims)
+  gin = zeros(query.qc_input.vardim); gout = zeros(1); gac1 = zeros(qb.vardim); gac2 = zeros(qs.vardim)
+  Z = zeros(Zdim, Zdim)
+  mode = opts.dense ? Int32(0) : (opts.decomp_mode isa SingleDecomp ? Int32(1) : Int32(2))
+  copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
+                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.verbose, opts.device)
+  res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
+                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0)
+  GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin
+    p(v) = isempty(v) ? Ptr{Float64}(C_NULL) : pointer(v)
+    prob = CProblem(ffnet.K, pointer(xdims), pointer(M), pointer(x1min), pointer(x1max), pointer(acymin), pointer(acymax),
+                    pointer(smin), pointer(smax), Int32(qs.β), qkind, okind, p(normal), p(yc), p(invP), p(S))
+    rc = ccall((:nnsdp_solve, LIBNNSDP), Cint, (Ref{CProblem}, Ref{COptions}, Ref{CResult}), prob, copts, res)
+    rc == 0 || error("nnsdp_solve failed ($rc): " * unsafe_string(ccall((:nnsdp_last_error, LIBNNSDP), Cstring, ())))
+  end
+  values = Dict{Symbol,Any}(:γin => gin, :γac1 => gac1, :γac2 => gac2, :Z => Z)
+  if query isa ReachQuery; values[:γout] = gout end
+  status = unsafe_string(ccall((:nnsdp_status_string, LIBNNSDP), Cstring, (Int32,), res.status))
+  if opts.verbose
+    println("setup: $(round(res.t_setup, digits=3)) \tsolve: $(round(res.t_solve, digits=3)) \ttotal: $(round(res.t_total, digits=3)) \t" *
+            "obj: $(round(res.objective, digits=5)) ($(status)) \tλmax: $(round(res.lambda_max, digits=7))")
+  end
+  return QuerySolution(model = nothing, objective_value = res.objective, values = values, summary = res,
+                       termination_status = status, total_time = res.t_total, setup_time = res.t_setup, solve_time = res.t_solve)
+end
