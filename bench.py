@@ -160,8 +160,10 @@ def main():
         s2 = na.runQuery(q, o2)
         out["time_to_cert"] = {"wall_s": time.perf_counter() - t1, "setup_s": s2.setup_time, "solve_s": s2.solve_time,
                                "status": s2.termination_status, "iters": s2.summary["iters"], "rho": s2.objective_value,
+                               "rho_admm_iterate": s2.summary["objective_admm"], "polish_shift": s2.summary["polish_shift"],
                                "pres": s2.summary["pres"], "dres": s2.summary["dres"], "lambda_max": s2.summary["lambda_max"],
-                               "eps": "pres,dres <= 1e-6 relative; lambda_max = eigmax(Z(gamma)) in the reference's coordinates"}
+                               "eps": "ADMM to pres,dres <= 1e-6 relative, then the feasibility polish; rho is the objective of the polished (feasible) point; "
+                                      "lambda_max = eigmax(Z(gamma)) in the reference's coordinates"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds)
     elif rank == 0:

@@ -78,6 +78,7 @@ typedef struct nnsdp_options {
   int32_t warm_start;     /* 1: warm-start each eigendecomposition from the previous eigenvectors */
   double proj_tol;        /* Jacobi stops at off(A) <= proj_tol |A|_F; 0 = adaptive: 0.01 x the current residual,
                              clamped to [1e-9, 1e-4] (inexact projections well below the residual level) */
+  int32_t polish;         /* 1: make the returned (gamma, Z) exactly feasible (diagonal shift + Schur complement for gout) */
   int32_t verbose;        /* QueryOptions.verbose (src/Methods/Methods.jl:110) */
   int32_t device;         /* HIP device ordinal, -1 = current */
 } nnsdp_options;
@@ -108,6 +109,8 @@ typedef struct nnsdp_result {
   int64_t eig_flops_per_iter; /* 10 * sum n_k^3 over the blocks solved */
   int64_t eig_bytes_per_iter; /* 2 * 8 * sum n_k^2 */
   double avg_sweeps;      /* Jacobi sweeps per block per iteration, averaged over the solve */
+  double objective_admm;  /* objective of the raw ADMM iterate (before the polish) */
+  double polish_shift;    /* diagonal shift applied by the polish in solver coordinates; -1: polish not applied */
 } nnsdp_result;
 
 int nnsdp_version(void);

@@ -22,6 +22,7 @@ const LIBNNSDP = get(ENV, "NNSDP_LIB", "libnnsdp_hip.so")
   normalize::Bool = true
   warm_start::Bool = true
   proj_tol::Float64 = 0.0
+  polish::Bool = true
   verbose::Bool = false
   device::Int = -1
 end
@@ -37,13 +38,14 @@ end
 struct COptions
   decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
   adapt_every::Int32; check_every::Int32; normalize::Int32; warm_start::Int32; proj_tol::Float64
-  verbose::Int32; device::Int32
+  polish::Int32; verbose::Int32; device::Int32
 end
 mutable struct CResult
   gamma_in::Ptr{Float64}; gamma_out::Ptr{Float64}; gamma_ac1::Ptr{Float64}; gamma_ac2::Ptr{Float64}; Z::Ptr{Float64}
   objective::Float64; status::Int32; iters::Int32; pres::Float64; dres::Float64; lambda_max::Float64
   t_setup::Float64; t_solve::Float64; t_total::Float64; t_eig::Float64
   n_cliques::Int32; max_clique::Int32; eig_flops_per_iter::Int64; eig_bytes_per_iter::Int64; avg_sweeps::Float64
+  objective_admm::Float64; polish_shift::Float64
 end
 
 function runQuery(query::Query, opts::AdmmSdpOptions)
@@ -72,9 +74,9 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   Z = zeros(Zdim, Zdim)
   mode = opts.dense ? Int32(0) : (opts.decomp_mode isa SingleDecomp ? Int32(1) : Int32(2))
   copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
-                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.verbose, opts.device)
+                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.verbose, opts.device)
   res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
-                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0)
+                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0)
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin
     p(v) = isempty(v) ? Ptr{Float64}(C_NULL) : pointer(v)
     prob = CProblem(ffnet.K, pointer(xdims), pointer(M), pointer(x1min), pointer(x1max), pointer(acymin), pointer(acymax),

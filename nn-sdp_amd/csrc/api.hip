@@ -456,11 +456,112 @@ struct nnsdp_solver {
     return status;
   }
 
+  // ---- certificate polish -------------------------------------------------------------------
+  // ADMM stops at a relative residual, so Z(gamma) is only approximately NSD.  The polish makes it NSD
+  // to rounding with two exact moves in the solver's coordinates (a congruence of the reference's, so
+  // definiteness carries over): (1) every coordinate i has a multiplier whose generator is a pure
+  // negative diagonal on (i,i) (gin_i / gac1_t): raise them until Z_xx <= -margin; (2) reach queries:
+  // gout only moves Z_aa, so the smallest feasible value follows from the Schur complement
+  //   Z_aa - z_xa' Z_xx^-1 z_xa <= 0.
+  // The result is a primal-feasible point: its objective is a valid (slightly conservative) bound.
+  double polish_shift = 0.0, objective_admm = 0.0;
+  void dense_from_gs(const std::vector<double>& gsh, DBuf<double>& Zt) {
+    int n = pat.n;
+    DBuf<double> gd, zd;
+    gd.upload(gsh);
+    zd.alloc(S.NE);
+    if (Zt.n != (size_t)n * n) Zt.alloc((size_t)n * n);
+    HIPCHK(hipMemsetAsync(Zt.p, 0, Zt.n * sizeof(double), st));
+    hipLaunchKernelGGL(k_apply_A, dim3(cdiv((long long)S.NE * 16, kThreads)), dim3(kThreads), 0, st, S.NE, D.csr_ptr.p, D.csr_col.p,
+                       D.csr_val.p, gd.p, D.z0.p, zd.p);
+    hipLaunchKernelGGL(k_scatter_dense, dim3(cdiv(S.NE, 256)), dim3(256), 0, st, S.NE, n, D.erow.p, D.ecol.p, zd.p, Zt.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  bool polish(std::vector<double>& gsh) {
+    int n = pat.n, nx = n - 1;
+    if (nx < 1) return false;
+    // kept-generator index of the diagonal-shift multiplier of each reduced coordinate, and of gout
+    std::vector<int> inv(P.ng, -1);
+    for (int i = 0; i < S.ng; ++i) inv[S.keep[i]] = i;
+    std::vector<int> shift_gen(nx, -1);
+    for (int i = 0; i < P.Zdim - 1; ++i) {
+      int ri = C.newpos[i];
+      if (ri < 0 || ri >= nx) continue;
+      int full = i < P.nin ? i : P.nin + P.nout + (i - P.nin);
+      shift_gen[ri] = inv[full];
+    }
+    auto entry = [&](int e, int g) -> double {   // A_s[e, g]
+      for (int q = S.csr_ptr[e]; q < S.csr_ptr[e + 1]; ++q) if (S.csr_col[q] == g) return S.csr_val[q];
+      return 0.0;
+    };
+    std::vector<double> dcoef(nx, 0.0);
+    for (int i = 0; i < nx; ++i) {
+      if (shift_gen[i] < 0) return false;
+      dcoef[i] = entry(pat.pos(i, i), shift_gen[i]);
+      if (!(dcoef[i] < 0.0)) return false;
+    }
+    int jout = P.nout ? inv[P.nin] : -1;
+    double aout = jout >= 0 ? entry(pat.pos(nx, nx), jout) : 0.0;
+    if (P.nout && !(aout < 0.0)) return false;
+    DBuf<double> Zt, W, Dv, Ev;
+    DBuf<rocblas_int> info;
+    info.alloc(1); Dv.alloc(nx); Ev.alloc(nx); W.alloc((size_t)nx * nx);
+    if (jout >= 0) gsh[jout] = 0.0;
+    dense_from_gs(gsh, Zt);
+    // (1) lambda_max of the x-block
+    HIPCHK(hipMemcpy2D(W.p, (size_t)nx * sizeof(double), Zt.p, (size_t)n * sizeof(double), (size_t)nx * sizeof(double), nx, hipMemcpyDeviceToDevice));
+    RBCHK(rocsolver_dsyevd(roc->h, rocblas_evect_none, rocblas_fill_lower, nx, W.p, nx, Dv.p, Ev.p, info.p));
+    HIPCHK(hipStreamSynchronize(st));
+    double lmax = Dv.download().back();
+    const double margin = 1e-9;
+    double delta = lmax > -margin ? lmax + margin + 1e-3 * std::fabs(lmax) : 0.0;
+    polish_shift = delta;
+    if (delta > 0.0) {
+      for (int i = 0; i < nx; ++i) gsh[shift_gen[i]] += delta / (-dcoef[i]);
+      dense_from_gs(gsh, Zt);
+    }
+    if (jout < 0) return true;
+    // (2) Schur complement for gout:  -Z_xx = L L',  need Z_aa + |L^-1 z_xa|^2 + gout * aout <= 0
+    std::vector<double> Zh((size_t)n * n);
+    HIPCHK(hipMemcpy(Zh.data(), Zt.p, Zh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> Nx((size_t)nx * nx);
+    for (int j = 0; j < nx; ++j)
+      for (int i = 0; i < nx; ++i) Nx[(size_t)j * nx + i] = -Zh[(size_t)j * n + i];
+    HIPCHK(hipMemcpy(W.p, Nx.data(), Nx.size() * sizeof(double), hipMemcpyHostToDevice));
+    RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, nx, W.p, nx, info.p));
+    HIPCHK(hipStreamSynchronize(st));
+    if (info.download()[0] != 0) return false;
+    std::vector<double> zxa(nx);
+    for (int i = 0; i < nx; ++i) zxa[i] = Zh[(size_t)nx * n + i];
+    DBuf<double> yv;
+    yv.upload(zxa);
+    RBCHK(rocblas_dtrsv(roc->h, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, nx, W.p, nx, yv.p, 1));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<double> y = yv.download();
+    double q = 0.0;
+    for (double v : y) q += v * v;
+    double need = (Zh[(size_t)nx * n + nx] + q) / (-aout);
+    gsh[jout] = std::max(0.0, need * (1.0 + 1e-12) + 1e-300);
+    return true;
+  }
+
   void finish(nnsdp_result* r, int status) {
     int ng = S.ng;
     hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(ng, 256)), dim3(256), 0, st, ng, nu.p, d_sigma(), gs.p);
     HIPCHK(hipStreamSynchronize(st));
     std::vector<double> gsh = gs.download();
+    {
+      double o = 0.0;
+      for (int i = 0; i < ng; ++i) o += S.c[i] * gsh[i];
+      objective_admm = o / (S.zscale * S.cscale);
+    }
+    bool polished = false;
+    if (opt.polish) {
+      std::vector<double> gp = gsh;
+      polished = polish(gp);
+      if (polished) gsh = gp;
+    }
     std::vector<double> gam(P.ng, 0.0);
     for (int i = 0; i < ng; ++i) gam[S.keep[i]] = gsh[i] * S.ecol[i] / S.zscale;
     // final Z and certificate in the reference's coordinates
@@ -521,7 +622,9 @@ struct nnsdp_solver {
     r->eig_bytes_per_iter = b;
     {
       std::vector<int> stv = d_stats.download();
-      r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
+      r->objective_admm = objective_admm;
+    r->polish_shift = polished ? polish_shift : -1.0;
+    r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
     }
   }
 
@@ -587,6 +690,7 @@ void nnsdp_default_options(nnsdp_options* o) {
   o->normalize = 1;
   o->warm_start = 1;
   o->proj_tol = 0.0;
+  o->polish = 1;
   o->verbose = 0;
   o->device = -1;
 }

@@ -121,9 +121,6 @@ __device__ __forceinline__ int pair_bot(int ia, int r, int M, int half) { return
 template <bool V_LDS, int NT>
 __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   extern __shared__ double lds[];
-  constexpr int TB = (NT == 1024) ? 32 : 16;   // block-update mapping: TA x TB threads
-  constexpr int TA = NT / TB;
-  constexpr int VP = (NT - 64) / 32;           // pair-slots processed at once by the V update
   const int k = blockIdx.x;
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // even

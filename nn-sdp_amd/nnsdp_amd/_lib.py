@@ -38,7 +38,7 @@ class Options(C.Structure):
         ("decomp_mode", C.c_int32), ("max_iters", C.c_int32), ("eps_rel", C.c_double),
         ("max_time", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
         ("adapt_every", C.c_int32), ("check_every", C.c_int32), ("normalize", C.c_int32),
-        ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("verbose", C.c_int32), ("device", C.c_int32),
+        ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("polish", C.c_int32), ("verbose", C.c_int32), ("device", C.c_int32),
     ]
 
 
@@ -50,7 +50,7 @@ class Result(C.Structure):
         ("pres", C.c_double), ("dres", C.c_double), ("lambda_max", C.c_double),
         ("t_setup", C.c_double), ("t_solve", C.c_double), ("t_total", C.c_double), ("t_eig", C.c_double),
         ("n_cliques", C.c_int32), ("max_clique", C.c_int32),
-        ("eig_flops_per_iter", C.c_int64), ("eig_bytes_per_iter", C.c_int64), ("avg_sweeps", C.c_double),
+        ("eig_flops_per_iter", C.c_int64), ("eig_bytes_per_iter", C.c_int64), ("avg_sweeps", C.c_double), ("objective_admm", C.c_double), ("polish_shift", C.c_double),
     ]
 
 

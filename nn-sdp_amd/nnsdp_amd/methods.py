@@ -184,6 +184,7 @@ class AdmmSdpOptions:
     normalize: bool = True
     warm_start: bool = True
     proj_tol: float = 0.0          # 0 = adaptive (see include/nnsdp.h)
+    polish: bool = True            # exact-feasibility polish of the returned certificate
     verbose: bool = False
     device: int = -1
 
@@ -201,6 +202,7 @@ class AdmmSdpOptions:
         o.normalize = int(bool(self.normalize))
         o.warm_start = int(bool(self.warm_start))
         o.proj_tol = float(self.proj_tol)
+        o.polish = int(bool(self.polish))
         o.verbose = int(bool(self.verbose))
         o.device = int(self.device)
         return o
@@ -315,7 +317,7 @@ def _solution(cp: _CProblem, r, bufs) -> QuerySolution:
     summary = dict(iters=r.iters, pres=r.pres, dres=r.dres, lambda_max=r.lambda_max, t_eig=r.t_eig,
                    n_cliques=r.n_cliques, max_clique=r.max_clique,
                    eig_flops_per_iter=r.eig_flops_per_iter, eig_bytes_per_iter=r.eig_bytes_per_iter,
-                   avg_sweeps=r.avg_sweeps)
+                   avg_sweeps=r.avg_sweeps, objective_admm=r.objective_admm, polish_shift=r.polish_shift)
     return QuerySolution(objective_value=r.objective, values=values,
                          termination_status=lib.nnsdp_status_string(r.status).decode(),
                          total_time=r.t_total, setup_time=r.t_setup, solve_time=r.t_solve, summary=summary)

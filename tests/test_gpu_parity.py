@@ -149,7 +149,7 @@ def _oracle_solve(d, mode, iters, **kw):
 @pytest.mark.parametrize("name,beta,iters", [("W10-D5", 0, 1500), ("W10-D5", 3, 800), ("W10-D10", 0, 1000)])
 def test_admm_tracks_oracle_iteration_for_iteration(name, beta, iters):
     d = helpers.load_problem(name, beta)
-    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=iters, proj_tol=1e-12))   # exact projections
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=iters, proj_tol=1e-12, polish=False))   # exact projections, raw iterate
     r = _oracle_solve(d, "single", iters)
     assert s.summary["iters"] == r.iters
     assert s.termination_status == r.status
@@ -188,7 +188,7 @@ def test_other_queries_track_oracle(out):
         kw["S"] = qc.hplane_S([1.0, 0.0], 10.0, net)          # y_1 <= 10: comfortably safe
     # compared at convergence: mid-trajectory iterates of these tiny-objective problems are sensitive to
     # the (deliberately inexact, 1e-10) projection tolerance of the HIP kernel
-    s = na.runQuery(helpers.product_query(d, out=out, **kw), na.AdmmSdpOptions(max_iters=8000))
+    s = na.runQuery(helpers.product_query(d, out=out, **kw), na.AdmmSdpOptions(max_iters=8000, polish=False))
     r = _oracle_solve(d, "single", 8000, out=out, **kw)
     assert s.termination_status == "OPTIMAL" and r.status == "OPTIMAL"
     assert abs(s.objective_value - r.objective) <= 1e-4 * abs(r.objective) + 1e-9
@@ -198,7 +198,7 @@ def test_other_queries_track_oracle(out):
 def test_unnormalised_solver_tracks_oracle():
     """normalize=0 runs the ADMM in the reference's own coordinates (blocks up to the nominal clique size)."""
     d = helpers.load_problem("W10-D5", 0)
-    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=300, normalize=False, sigma=1.0, adapt_every=0, proj_tol=1e-12))
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=300, normalize=False, sigma=1.0, adapt_every=0, proj_tol=1e-12, polish=False))
     qo = helpers.oracle_query(d)
     L = oop.build_operator(qo, "single", normalize=False)
     P = oadmm.ScaledProblem.__new__(oadmm.ScaledProblem)
@@ -224,6 +224,27 @@ def test_published_objective_w10_d10():
     s = na.runQuery(helpers.product_query(helpers.load_problem("W10-D10", 0)), na.AdmmSdpOptions(max_iters=12000))
     assert min(abs(s.objective_value - p) / p for p in pub) <= 1e-3, (s.objective_value, pub)
     assert s.summary["pres"] <= 1e-5 and s.summary["dres"] <= 1e-5
+
+
+@pytest.mark.parametrize("name,beta,iters", [("W10-D5", 0, 3000), ("W10-D10", 0, 12000), ("W20-D10", 0, 12000)])
+def test_polished_certificate_is_feasible(name, beta, iters):
+    """the returned (gamma, Z) is a certificate in the reference's sense (Methods.jl:116, acas.jl:76-79):
+    gamma >= 0 and eigmax(Z(gamma)) <= tolerance in the reference's coordinates, and the polish costs
+    less than 1e-3 of the objective once ADMM has converged."""
+    d = helpers.load_problem(name, beta)
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=iters))
+    gam = np.concatenate([s.values["γin"], s.values["γout"], s.values["γac1"], s.values["γac2"]])
+    assert gam.min() >= 0.0
+    Z = s.values["Z"]
+    scale = np.abs(Z).max()
+    lmax = np.linalg.eigvalsh(Z).max()
+    assert lmax <= 1e-6, lmax                                  # the reference's OPTIMAL rows sit at 1e-7 ... 5e-6
+    assert abs(lmax - s.summary["lambda_max"]) <= 1e-9 * max(1.0, scale)
+    assert s.summary["polish_shift"] >= 0.0
+    # a feasible point bounds the optimum from above; it must stay close to the ADMM value
+    ra = s.summary["objective_admm"]
+    assert s.objective_value >= ra * (1 - 1e-6) - 1e-12
+    assert s.objective_value - ra <= 2e-3 * abs(ra), (s.objective_value, ra)
 
 
 def test_full_size_solver_invariants_w40_d20():
