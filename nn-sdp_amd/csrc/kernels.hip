@@ -19,6 +19,8 @@ static constexpr int kThreads = 256;
 static constexpr double kSqrt2 = 1.41421356237309504880;
 static constexpr double kInvSqrt2 = 0.70710678118654752440;
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -123,24 +125,28 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   extern __shared__ double lds[];
   const int k = blockIdx.x;
   const int n = a.cn[k];
-  const int np = (n + 1) & ~1;   // even
+  const int np = (n + 1) & ~1;   // Jacobi dimension (even)
+  const int npg = (n + 15) & ~15;  // storage / MFMA dimension (multiple of 16; zero rows, identity in V)
   const int half = np >> 1;
-  const int lda = np + 1;        // odd stride (in doubles): column walks hit distinct banks
+  const int lda = npg + 1;       // odd stride (in doubles): column walks hit distinct banks
   const int tid = threadIdx.x;
   double* A = lds;
-  double* desc = A + (size_t)np * lda;          // 2 buffers x half pair descriptors {c, s, (p, q)} = 3 doubles each
-  double* red = desc + 3 * np;                  // 16 doubles of reduction scratch
-  int* sel = reinterpret_cast<int*>(red + 16);  // np + 2 ints: eigen-indices on the chosen side, counters
+  double* desc = A + (size_t)npg * lda;         // 2 buffers x half pair descriptors {c, s, (p, q)} = 3 doubles each
+  double* red = desc + 3 * npg;                  // 16 doubles of reduction scratch
+  int* sel = reinterpret_cast<int*>(red + 16);  // npg + 2 ints: eigen-indices on the chosen side, counters
   double* V;
   int ldv;
-  if (V_LDS) { V = red + 16 + (np >> 1) + 2; ldv = np + 1; }
+  if (V_LDS) { V = red + 16 + (npg >> 1) + 2; ldv = npg + 1; }
   else { V = a.Vg + a.coff[k]; ldv = n; }
   const double* nuk = a.nu + a.coff[k];
 
+#ifdef NNSDP_STAMPS
+  long long sec_t[6]; sec_t[0] = clock64();
+#endif
   // ---- load: A = sym(nu_k) (full, both triangles, for the warm-start products), padded row/col zero
   double fro2 = 0.0;
-  for (int j = tid >> 6; j < np; j += NT >> 6)
-    for (int i = tid & 63; i < np; i += 64) {
+  for (int j = tid >> 6; j < npg; j += NT >> 6)
+    for (int i = tid & 63; i < npg; i += 64) {
       double v = 0.0;
       if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
       A[i * lda + j] = v;
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   // ---- starting basis
   const bool warm = a.warm != 0;
   if (V_LDS) {
-    for (int j = tid >> 6; j < np; j += NT >> 6)
-      for (int i = tid & 63; i < np; i += 64) {
+    for (int j = tid >> 6; j < npg; j += NT >> 6)
+      for (int i = tid & 63; i < npg; i += 64) {
         double v = (i == j) ? 1.0 : 0.0;
         if (warm && i < n && j < n) v = a.Vg[a.coff[k] + (size_t)j * n + i];
         V[i + j * ldv] = v;
@@ -161,9 +167,73 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
       for (int i = tid & 63; i < n; i += 64) V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
+#ifdef NNSDP_STAMPS
+  sec_t[1] = clock64();
+#endif
   const int nv = V_LDS ? np : n;  // rows/cols of V that exist
-  if (warm) {
-    // A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
+  if (warm && V_LDS) {
+    // A <- V' A V with v_mfma_f64_16x16x4_f64: T = A V (all 16x16 tiles), then A' = V' T (lower tiles; the
+    // Jacobi sweeps read the lower triangle only).  Operand maps (verified on gfx950): lane l holds
+    // A[l&15][l>>4], B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
+    constexpr int NW = NT / 64;
+    constexpr int MAXT = 3;                    // ceil(36 tiles / 16 waves), ceil(9 / 4)
+    const int nt = npg >> 4, ks = npg >> 2;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int lr = lane & 15, lc = lane >> 4;
+    d4_t acc[MAXT];
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      int t = wv + m * NW;
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+      if (t < nt * nt) {
+        int ti = t / nt, tj = t - ti * nt;
+        const double* ap = A + (16 * ti + lr) * lda + lc;
+        const double* bp = V + lc + (size_t)(16 * tj + lr) * ldv;
+        for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk], c, 0, 0, 0);
+      }
+      acc[m] = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      int t = wv + m * NW;
+      if (t < nt * nt) {
+        int ti = t / nt, tj = t - ti * nt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(16 * ti + lc + 4 * r) * lda + 16 * tj + lr] = acc[m][r];
+      }
+    }
+    __syncthreads();
+    const int ntl = nt * (nt + 1) / 2;
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      int t = wv + m * NW;
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+      if (t < ntl) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        int tj = t - ti * (ti + 1) / 2;
+        const double* ap = V + lc + (size_t)(16 * ti + lr) * ldv;   // V'[i][k] = V[k][i]
+        const double* bp = A + lc * lda + 16 * tj + lr;             // T[k][j]
+        for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk * lda], c, 0, 0, 0);
+      }
+      acc[m] = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      int t = wv + m * NW;
+      if (t < ntl) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        int tj = t - ti * (ti + 1) / 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(16 * ti + lc + 4 * r) * lda + 16 * tj + lr] = acc[m][r];
+      }
+    }
+    __syncthreads();
+  } else if (warm) {
+    // (blocks too large to keep V in LDS) A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
     //   T = A V   (written over A),   A' = V' T   (written over T)
     constexpr int kTilesMax = 2048 / NT;               // (128/4) * (128/2) tiles at most
     const int ti_n = (np + 3) >> 2, tj_n = np >> 1;    // tile grid
@@ -231,6 +301,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     __syncthreads();
   }
 
+#ifdef NNSDP_STAMPS
+  sec_t[2] = clock64();
+#endif
   // ---- Jacobi sweeps (only the lower triangle of A is read and written from here on)
   const double tolv = a.tol_dev ? *a.tol_dev : a.tol;
   const double thresh2 = tolv * tolv * fro2;  // converged when off(A) <= tol |A|_F, measured directly before each sweep
@@ -374,10 +447,11 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     ++sweeps;
   }
 #ifdef NNSDP_STAMPS
+  sec_t[3] = clock64();
   if (k == 0 && (tid & 63) == 0 && a.eig) {   // debug build only: per-wave phase cycles into the tail of eig[]
     long long* dbg = reinterpret_cast<long long*>(a.eig + 4096);
     for (int i = 0; i < 4; ++i) dbg[(tid >> 6) * 4 + i] = st_acc[i];
-    if (tid == 0) dbg[64] = sweeps;
+    if (tid == 0) { dbg[64] = sweeps; dbg[65] = sec_t[1] - sec_t[0]; dbg[66] = sec_t[2] - sec_t[1]; dbg[67] = sec_t[3] - sec_t[2]; dbg[68] = sec_t[3]; }
   }
 #endif
   if (tid == 0 && a.stats) { atomicAdd(&a.stats[0], sweeps); atomicMax(&a.stats[1], sweeps); }
@@ -389,27 +463,62 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     bool use_pos = npos <= nneg;
     int cnt = 0;
     for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; if (use_pos ? (l > 0.0) : (l < 0.0)) sel[cnt++] = i; }
-    sel[np] = cnt;
-    sel[np + 1] = use_pos ? 1 : 0;
+    sel[npg] = cnt;
+    sel[npg + 1] = use_pos ? 1 : 0;
   }
   __syncthreads();
-  const int nsel = sel[np];
-  const bool use_pos = sel[np + 1] != 0;
+  const int nsel = sel[npg];
+  const bool use_pos = sel[npg + 1] != 0;
   if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[tid * lda + tid];
   const double kap = a.kappa ? *a.kappa : 1.0;
   double* wk = a.w + a.coff[k];
   double* nuw = a.nu + a.coff[k];
-  for (int j = tid >> 6; j < n; j += NT >> 6)
-    for (int i = tid & 63; i < n; i += 64) {
-      double s = 0.0;
-      for (int t = 0; t < nsel; ++t) {
-        int l = sel[t];
-        s += A[l * lda + l] * V[i + (size_t)l * ldv] * V[j + (size_t)l * ldv];
+  if (V_LDS) {
+    // W = sum_t lam_t v_t v_t' over the selected eigenpairs as MFMA tiles (K = nsel padded to 4); lower
+    // tiles are computed and mirrored; !use_pos: W = sym(nu) - (negative part)
+    constexpr int NW = NT / 64;
+    const int nt = (n + 15) >> 4, ntl = nt * (nt + 1) / 2, ks = (nsel + 3) >> 2;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int lr = lane & 15, lc = lane >> 4;
+    for (int t = wv; t < ntl; t += NW) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      int tj = t - ti * (ti + 1) / 2;
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < ks; ++kk) {
+        int tt = 4 * kk + lc;
+        double av = 0.0, bv = 0.0;
+        if (tt < nsel) {
+          int l = sel[tt];
+          av = A[l * lda + l] * V[16 * ti + lr + (size_t)l * ldv];
+          bv = V[16 * tj + lr + (size_t)l * ldv];
+        }
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
       }
-      double nij = nuk[(size_t)j * n + i], nji = nuk[(size_t)i * n + j];
-      if (!use_pos) s = 0.5 * (nij + nji) - s;
-      wk[(size_t)j * n + i] = s;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 16 * ti + lc + 4 * r, col = 16 * tj + lr;
+        if (row < n && col < n) {
+          double v = c[r];
+          if (!use_pos) v = 0.5 * (nuk[(size_t)col * n + row] + nuk[(size_t)row * n + col]) - v;
+          wk[(size_t)col * n + row] = v;
+          if (ti != tj) wk[(size_t)row * n + col] = v;
+        }
+      }
     }
+  } else {
+    for (int j = tid >> 6; j < n; j += NT >> 6)
+      for (int i = tid & 63; i < n; i += 64) {
+        double s = 0.0;
+        for (int t = 0; t < nsel; ++t) {
+          int l = sel[t];
+          s += A[l * lda + l] * V[i + (size_t)l * ldv] * V[j + (size_t)l * ldv];
+        }
+        double nij = nuk[(size_t)j * n + i], nji = nuk[(size_t)i * n + j];
+        if (!use_pos) s = 0.5 * (nij + nji) - s;
+        wk[(size_t)j * n + i] = s;
+      }
+  }
   if (kap != 1.0) {
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += NT) { double wv = wk[idx]; nuw[idx] = wv + kap * (nuw[idx] - wv); }
@@ -419,6 +528,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     for (int j = tid >> 6; j < n; j += NT >> 6)
       for (int i = tid & 63; i < n; i += 64) vg[(size_t)j * n + i] = V[i + j * ldv];
   }
+#ifdef NNSDP_STAMPS
+  if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
+#endif
 }
 
 // launch: NT = 1024 for blocks above kSmallBlock, 256 below
@@ -444,7 +556,7 @@ inline hipError_t proj_allow_big_lds() {
 }
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds) {
-  int np = (nmax + 1) & ~1;
+  int np = (nmax + 15) & ~15;
   size_t d = (size_t)np * (np + 1) + 3 * np + 16 + (np >> 1) + 2;   // A, desc[2][half][3], red, sel[np+2] (ints)
   if (v_lds) d += (size_t)np * (np + 1);
   return d * sizeof(double);

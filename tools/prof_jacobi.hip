@@ -22,12 +22,21 @@ int main(int argc, char** argv) {
   proj_allow_big_lds();
   ProjArgs a; a.cn = dcn; a.coff = dco; a.eoff = deo; a.nu = dnu; a.w = dw; a.Vg = dV; a.eig = dE; a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; ++rep) {
+  for (int rep = 0; rep < 4; ++rep) {
+    if (rep >= 2) {  // warm regime: perturb the matrices slightly, start from the stored eigenvectors, solver tolerance
+      double eps = argc > 3 ? atof(argv[3]) : 1e-3;
+      for (auto& v : h) v *= (1.0 + eps * nd(rng));
+      for (int b = 0; b < batch; ++b) for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) h[(size_t)b*n*n + i*n + j] = h[(size_t)b*n*n + j*n + i];
+      hipMemcpy(dnu, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+      a.warm = 1; a.tol = argc > 4 ? atof(argv[4]) : 1e-6;
+    }
     hipEventRecord(e0); launch_proj(a, batch, n, v_lds, lds, nullptr); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long dbg[65]; hipMemcpy(dbg, dE + 4096, sizeof(dbg), hipMemcpyDeviceToHost);
+    long long dbg[70]; hipMemcpy(dbg, dE + 4096, sizeof(dbg), hipMemcpyDeviceToHost);
     printf("n=%d batch=%d v_lds=%d kernel %.3f ms sweeps %lld -> %.1f us/sweep\n", n, batch, (int)v_lds, ms, dbg[64], 1e3 * ms / dbg[64]);
 #ifdef NNSDP_STAMPS
+    printf("  sections (cycles, wave 0): load+basis %lld  warm-GEMM %lld  sweeps %lld  reconstruct+store %lld\n", dbg[65], dbg[66], dbg[67], dbg[69]);
+    if (rep != 1 && rep != 3) continue;
     int nw = n > kSmallBlock ? 16 : 4;
     long long rounds = dbg[64] * (((n + 1) & ~1) - 1);
     for (int w = 0; w < nw; ++w) printf("  wave %2d cycles/round: phase1 %6.0f barrier %6.0f phase2 %6.0f barrier %6.0f\n", w,
