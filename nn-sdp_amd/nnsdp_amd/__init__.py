@@ -6,6 +6,10 @@ from .methods import (  # noqa: F401
     SingleDecomp, DoubleDecomp, DenseCone, Solver,
     runQuery, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched,
 )
+from .frontend import (  # noqa: F401
+    read_nnet, evalFeedFwdNet, makeIntervalsInfo, makeQcActivs, approxEllipsoid,
+    findEllipsoid, findCircle, findReach2Dpoly, write_scale_csv,
+)
 from . import _lib  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,79 @@
+"""Rows f1-f3 of SURVEY.md section 8: the product's host-side .nnet reader, CROWN-sliced intervals and QC
+construction against the oracle restatement and the committed fixtures (CPU), and the findEllipsoid
+front-end end to end on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+import nnsdp_amd as na
+from oracle import intervals as ointv, nnet_io
+
+
+def _nnet_text(net, path):
+    # the reference writer's layout (exts/NNet/utils/writeNNet.py:3-80, '%.9f' values)
+    with open(path, "w") as f:
+        f.write("// Neural Network File Format by Kyle Julian, Stanford 2016\n")
+        f.write(f"{len(net.Ms)},{net.xdims[0]},{net.xdims[-1]},{max(net.xdims)},\n")
+        f.write(",".join(str(v) for v in net.xdims) + ",\n0,\n")
+        f.write(",".join(["-10000.0"] * net.xdims[0]) + ",\n" + ",".join(["10000.0"] * net.xdims[0]) + ",\n")
+        f.write(",".join(["0.0"] * (net.xdims[0] + 1)) + ",\n" + ",".join(["1.0"] * (net.xdims[0] + 1)) + ",\n")
+        for Mk in net.Ms:
+            for row in Mk[:, :-1]:
+                f.write(",".join("%.9f" % v for v in row) + ",\n")
+            for v in Mk[:, -1]:
+                f.write("%.9f,\n" % v)
+
+
+def test_nnet_reader_roundtrip(tmp_path):
+    ref = nnet_io.load_npz(os.path.join(helpers.GOLDEN, "nets", "scale-I2-O2-W10-D5.npz"))
+    p = str(tmp_path / "net.nnet")
+    _nnet_text(ref, p)
+    net = na.read_nnet(p)
+    assert net.xdims == ref.xdims
+    for a, b in zip(net.Ms, ref.Ms):
+        assert np.array_equal(a, b)                       # the fixture holds exactly the %.9f values
+    o = nnet_io.read_nnet(p)
+    x = np.array([0.7, 1.2])
+    assert np.allclose(na.evalFeedFwdNet(net, x), nnet_io.eval_net(o, x), rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name,beta", [("W10-D5", 0), ("W10-D10", 2), ("W20-D10", 0)])
+def test_intervals_and_qcs_match_fixture_and_oracle(name, beta):
+    d = helpers.load_problem(name, beta)
+    net = na.FeedFwdNet(xdims=[int(v) for v in d["xdims"]], Ms=helpers.problem_Ms(d))
+    qb, qs = na.makeQcActivs(net, d["x1min"], d["x1max"], beta)
+    assert np.allclose(qb.acymin, d["acymin"], rtol=0, atol=2e-6) and np.allclose(qb.acymax, d["acymax"], rtol=0, atol=2e-6)
+    assert np.array_equal(qs.smin, d["smin"]) and np.array_equal(qs.smax, d["smax"])
+    assert qs.vardim == len(d["smin"]) * (beta + 3) - beta * (beta + 1) // 2
+    x_intvs, acx = na.makeIntervalsInfo(d["x1min"], d["x1max"], net)
+    o = ointv.intervals_crown_sliced(nnet_io.FeedFwdNet(xdims=net.xdims, Ms=net.Ms), d["x1min"], d["x1max"])
+    for (l, u), (lo, uo) in zip(x_intvs, o.x_intvs):
+        assert np.allclose(l, lo, rtol=0, atol=2e-6) and np.allclose(u, uo, rtol=0, atol=2e-6)
+
+
+def test_scale_csv_layout(tmp_path):
+    s = na.QuerySolution(objective_value=1.5, values={}, termination_status="OPTIMAL", total_time=3.0, setup_time=1.0,
+                         solve_time=2.0, summary={"lambda_max": 1e-9})
+    p = str(tmp_path / "x.csv")
+    na.write_scale_csv(p, [(0, s), (1, s)])
+    rows = open(p).read().strip().split("\n")
+    assert rows[0] == "beta,setup_secs,solve_secs,total_secs,obj_val,term_status,eigmax" and len(rows) == 3
+    ref_hdr = open(os.path.join(helpers.GOLDEN, "dump_scale.csv")).readline().strip().split(",")[2:]
+    assert rows[0].split(",") == ref_hdr                   # same columns as the reference's dump/scale files
+
+
+@pytest.mark.gpu
+def test_find_ellipsoid_end_to_end_gpu():
+    d = helpers.load_problem("W10-D10", 0)
+    net = na.FeedFwdNet(xdims=[int(v) for v in d["xdims"]], Ms=helpers.problem_Ms(d))
+    P, yc, soln = na.findEllipsoid(net, [0.5, 0.5], [1.5, 1.5], 0, na.AdmmSdpOptions(max_iters=12000, decomp_mode=na.DoubleDecomp()))
+    pub = helpers.published_rho("W10-D10", 0)
+    assert min(abs(soln.objective_value - p) / p for p in pub) <= 1.5e-3
+    assert soln.summary["lambda_max"] <= 1e-6
+    # every sampled output lies inside the certified set |invP y - yc|^2 <= rho (output.jl:91-93 form)
+    rng = np.random.default_rng(0)
+    Y = na.evalFeedFwdNet(net, 0.5 + rng.random((2, 20000)))
+    invP = np.linalg.inv(P / np.sqrt(soln.objective_value))
+    assert (np.sum((invP @ Y - yc[:, None]) ** 2, axis=0)).max() <= soln.objective_value * (1 + 1e-9)
