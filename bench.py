@@ -167,17 +167,20 @@ def main():
         # wall-clock to certificate on fresh solves (setup + ADMM to eps_rel = 1e-6 + feasibility polish)
         out["time_to_cert"] = {}
         for mode in (na.SingleDecomp(), na.DoubleDecomp()):
-            o2 = na.AdmmSdpOptions(decomp_mode=mode, max_iters=500000, max_time=args.cert_seconds, eps_rel=1e-6)
-            t1 = time.perf_counter()
-            s2 = na.runQuery(q, o2)
-            out["time_to_cert"][type(mode).__name__] = {
-                "wall_s": time.perf_counter() - t1, "setup_s": s2.setup_time, "solve_s": s2.solve_time,
-                "status": s2.termination_status, "iters": s2.summary["iters"], "rho": s2.objective_value,
-                "rho_admm_iterate": s2.summary["objective_admm"], "polish_shift": s2.summary["polish_shift"],
-                "pres": s2.summary["pres"], "dres": s2.summary["dres"], "lambda_max": s2.summary["lambda_max"],
-                "blocks": s2.summary["n_cliques"], "max_block": s2.summary["max_clique"]}
-        out["time_to_cert"]["eps"] = ("ADMM to pres,dres <= 1e-6 relative, then the feasibility polish; rho = objective of the "
-                                      "polished (feasible) point; lambda_max = eigmax(Z(gamma)) in the reference's coordinates")
+            for rule, kw in (("residual_1e-6", dict(eps_rel=1e-6)), ("certified_gap_1e-3", dict(eps_rel=1e-6, cert_tol=1e-3))):
+                o2 = na.AdmmSdpOptions(decomp_mode=mode, max_iters=500000, max_time=args.cert_seconds, **kw)
+                t1 = time.perf_counter()
+                s2 = na.runQuery(q, o2)
+                out["time_to_cert"][f"{type(mode).__name__}/{rule}"] = {
+                    "wall_s": time.perf_counter() - t1, "setup_s": s2.setup_time, "solve_s": s2.solve_time,
+                    "status": s2.termination_status, "iters": s2.summary["iters"], "rho": s2.objective_value,
+                    "rho_admm_iterate": s2.summary["objective_admm"], "polish_shift": s2.summary["polish_shift"],
+                    "pres": s2.summary["pres"], "dres": s2.summary["dres"], "lambda_max": s2.summary["lambda_max"],
+                    "blocks": s2.summary["n_cliques"], "max_block": s2.summary["max_clique"]}
+        out["time_to_cert"]["eps"] = ("residual_1e-6: ADMM to pres,dres <= 1e-6 relative, then the feasibility polish. "
+                                      "certified_gap_1e-3: stop as soon as the polished (exactly feasible) objective is within 1e-3 of the "
+                                      "ADMM primal/dual estimates. rho = objective of the polished point; lambda_max = eigmax(Z(gamma)) "
+                                      "in the reference's coordinates (reference acceptance: 1e-6 .. 1e-4)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds)
     elif rank == 0:

@@ -79,6 +79,8 @@ typedef struct nnsdp_options {
   double proj_tol;        /* Jacobi stops at off(A) <= proj_tol |A|_F; 0 = adaptive: 0.01 x the current residual,
                              clamped to [1e-9, 1e-4] (inexact projections well below the residual level) */
   int32_t polish;         /* 1: make the returned (gamma, Z) exactly feasible (diagonal shift + Schur complement for gout) */
+  double cert_tol;        /* > 0 (reach queries): also stop once the polished, exactly feasible objective is within
+                             cert_tol (relative) of the ADMM primal/dual objective estimates; 0 = residual test only */
   int32_t verbose;        /* QueryOptions.verbose (src/Methods/Methods.jl:110) */
   int32_t device;         /* HIP device ordinal, -1 = current */
 } nnsdp_options;

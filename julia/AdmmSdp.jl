@@ -23,6 +23,7 @@ const LIBNNSDP = get(ENV, "NNSDP_LIB", "libnnsdp_hip.so")
   warm_start::Bool = true
   proj_tol::Float64 = 0.0
   polish::Bool = true
+  cert_tol::Float64 = 0.0
   verbose::Bool = false
   device::Int = -1
 end
@@ -38,7 +39,7 @@ end
 struct COptions
   decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
   adapt_every::Int32; check_every::Int32; normalize::Int32; warm_start::Int32; proj_tol::Float64
-  polish::Int32; verbose::Int32; device::Int32
+  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32
 end
 mutable struct CResult
   gamma_in::Ptr{Float64}; gamma_out::Ptr{Float64}; gamma_ac1::Ptr{Float64}; gamma_ac2::Ptr{Float64}; Z::Ptr{Float64}
@@ -74,7 +75,7 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   Z = zeros(Zdim, Zdim)
   mode = opts.dense ? Int32(0) : (opts.decomp_mode isa SingleDecomp ? Int32(1) : Int32(2))
   copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
-                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.verbose, opts.device)
+                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device)
   res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
                 0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0)
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin

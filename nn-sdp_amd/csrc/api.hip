@@ -175,7 +175,8 @@ struct nnsdp_solver {
   int graph_iters = 0;
   std::vector<hipEvent_t> ev;
   std::unique_ptr<RocHandle> roc;
-  long long iters_done = 0, next_adapt = 0;
+  long long iters_done = 0, next_adapt = 0, next_trace = 0, next_cert = 500;
+  int trace_polish = 0;
   int since_cold = 0;
   double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
   double last_pres = 1e300, last_dres = 1e300, last_pobj = 0, last_dobj = 0;
@@ -434,6 +435,7 @@ struct nnsdp_solver {
     int status = NNSDP_STATUS_ITERATION_LIMIT;
     int ce = opt.check_every;
     if (next_adapt == 0) next_adapt = opt.adapt_every;
+    if (const char* e = std::getenv("NNSDP_TRACE_POLISH")) trace_polish = std::atoi(e);
     while (iters_done < opt.max_iters) {
       int n = (int)std::min<long long>(ce - 1, opt.max_iters - iters_done - 1);
       iterate(n, nullptr);
@@ -443,7 +445,38 @@ struct nnsdp_solver {
                      last_dres, last_pobj, last_dobj, sigma);
       if (!(last_pres == last_pres) || !(last_dres == last_dres)) { status = NNSDP_STATUS_NUMERICAL_ERROR; break; }
       update_proj_tol();
+      if (trace_polish > 0 && iters_done >= next_trace) {
+        next_trace = iters_done + trace_polish;
+        double tp = now_s();
+        hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<double> gp = gs.download();
+        bool ok = polish(gp);
+        double o = 0.0;
+        for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
+        std::fprintf(stderr, "[nnsdp] it %6lld t %.2f polished rho %.8g (ok %d shift %.2e) admm %.8g dobj %.8g pres %.1e dres %.1e polish_ms %.0f\n", iters_done,
+                     now_s() - t0, o / (S.zscale * S.cscale), (int)ok, polish_shift, last_pobj, last_dobj, last_pres, last_dres, 1e3 * (now_s() - tp));
+      }
       if (last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
+      // optional early stop on the CERTIFIED objective: the polished point is exactly feasible, so once it
+      // is within cert_tol of the ADMM estimate of the optimum the certificate is as good as it gets
+      if (opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= 1e-3) {
+        next_cert = std::max<long long>(iters_done + 250, iters_done * 5 / 4);
+        hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<double> gp = gs.download();
+        if (polish(gp)) {
+          double o = 0.0;
+          for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
+          o /= (S.zscale * S.cscale);
+          double ref = std::max(std::fabs(last_pobj), std::fabs(last_dobj));
+          if (opt.verbose) std::fprintf(stderr, "[nnsdp] it %6lld certified rho %.8g  admm %.8g  dual %.8g\n", iters_done, o, last_pobj, last_dobj);
+          if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) {
+            status = NNSDP_STATUS_OPTIMAL;
+            break;
+          }
+        }
+      }
       if (opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
       // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
       if (opt.adapt_every > 0 && iters_done >= next_adapt) {
@@ -509,13 +542,43 @@ struct nnsdp_solver {
     info.alloc(1); Dv.alloc(nx); Ev.alloc(nx); W.alloc((size_t)nx * nx);
     if (jout >= 0) gsh[jout] = 0.0;
     dense_from_gs(gsh, Zt);
-    // (1) lambda_max of the x-block
+    // (1) eigen-decomposition of the x-block: Z_xx = Q diag(lam) Q'
     HIPCHK(hipMemcpy2D(W.p, (size_t)nx * sizeof(double), Zt.p, (size_t)n * sizeof(double), (size_t)nx * sizeof(double), nx, hipMemcpyDeviceToDevice));
-    RBCHK(rocsolver_dsyevd(roc->h, rocblas_evect_none, rocblas_fill_lower, nx, W.p, nx, Dv.p, Ev.p, info.p));
+    RBCHK(rocsolver_dsyevd(roc->h, jout >= 0 ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_lower, nx, W.p, nx, Dv.p, Ev.p, info.p));
     HIPCHK(hipStreamSynchronize(st));
-    double lmax = Dv.download().back();
+    std::vector<double> lam = Dv.download();
+    double lmax = lam.back();
     const double margin = 1e-9;
     double delta = lmax > -margin ? lmax + margin + 1e-3 * std::fabs(lmax) : 0.0;
+    if (jout >= 0) {
+      // uniform shift delta >= delta_min chosen to MINIMISE the certified objective
+      //   f(delta) = Z_aa + kappa*delta + sum_i c_i^2 / (mu_i + delta),   mu = -lam, c = Q' z_xa
+      // (convex on delta > -min mu): near convergence Z_xx is NSD but almost singular, and a small extra
+      // shift is much cheaper than the Schur term along the near-null directions
+      std::vector<double> Q = W.download(), zall = Zt.download();
+      std::vector<double> cvec(nx, 0.0);
+      for (int i = 0; i < nx; ++i) {
+        double sdot = 0.0;
+        const double* qi = &Q[(size_t)i * nx];
+        for (int r = 0; r < nx; ++r) sdot += qi[r] * zall[(size_t)nx * n + r];
+        cvec[i] = sdot * sdot;
+      }
+      double kappa = 0.0;
+      for (int i = 0; i < nx; ++i) kappa += entry(pat.pos(nx, nx), shift_gen[i]) / (-dcoef[i]);
+      auto fprime = [&](double dl) {
+        double sder = kappa;
+        for (int i = 0; i < nx; ++i) { double m = -lam[i] + dl; sder -= cvec[i] / (m * m); }
+        return sder;
+      };
+      double lo = delta;
+      if (fprime(lo) < 0.0) {
+        double hi = std::max(2.0 * lo, 1e-12);
+        int guard = 0;
+        while (fprime(hi) < 0.0 && guard++ < 200) hi *= 2.0;
+        for (int itb = 0; itb < 100; ++itb) { double mid = 0.5 * (lo + hi); if (fprime(mid) < 0.0) lo = mid; else hi = mid; }
+        delta = hi;
+      }
+    }
     polish_shift = delta;
     if (delta > 0.0) {
       for (int i = 0; i < nx; ++i) gsh[shift_gen[i]] += delta / (-dcoef[i]);
@@ -691,6 +754,7 @@ void nnsdp_default_options(nnsdp_options* o) {
   o->warm_start = 1;
   o->proj_tol = 0.0;
   o->polish = 1;
+  o->cert_tol = 0.0;
   o->verbose = 0;
   o->device = -1;
 }

@@ -38,7 +38,7 @@ class Options(C.Structure):
         ("decomp_mode", C.c_int32), ("max_iters", C.c_int32), ("eps_rel", C.c_double),
         ("max_time", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
         ("adapt_every", C.c_int32), ("check_every", C.c_int32), ("normalize", C.c_int32),
-        ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("polish", C.c_int32), ("verbose", C.c_int32), ("device", C.c_int32),
+        ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("polish", C.c_int32), ("cert_tol", C.c_double), ("verbose", C.c_int32), ("device", C.c_int32),
     ]
 
 

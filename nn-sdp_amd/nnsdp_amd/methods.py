@@ -185,6 +185,7 @@ class AdmmSdpOptions:
     warm_start: bool = True
     proj_tol: float = 0.0          # 0 = adaptive (see include/nnsdp.h)
     polish: bool = True            # exact-feasibility polish of the returned certificate
+    cert_tol: float = 0.0          # > 0: early stop on the certified objective (see include/nnsdp.h)
     verbose: bool = False
     device: int = -1
 
@@ -203,6 +204,7 @@ class AdmmSdpOptions:
         o.warm_start = int(bool(self.warm_start))
         o.proj_tol = float(self.proj_tol)
         o.polish = int(bool(self.polish))
+        o.cert_tol = float(self.cert_tol)
         o.verbose = int(bool(self.verbose))
         o.device = int(self.device)
         return o

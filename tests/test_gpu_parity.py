@@ -247,6 +247,20 @@ def test_polished_certificate_is_feasible(name, beta, iters):
     assert s.objective_value - ra <= 2e-3 * abs(ra), (s.objective_value, ra)
 
 
+def test_certified_gap_stopping_rule():
+    """cert_tol: stop as soon as the polished, exactly feasible objective is within 1e-3 of the ADMM estimates;
+    the result must be a valid certificate whose objective upper-bounds the converged optimum by <= 2e-3."""
+    d = helpers.load_problem("W10-D10", 0)
+    q = helpers.product_query(d)
+    full = na.runQuery(q, na.AdmmSdpOptions(max_iters=20000, decomp_mode=na.DoubleDecomp()))
+    fast = na.runQuery(q, na.AdmmSdpOptions(max_iters=20000, decomp_mode=na.DoubleDecomp(), cert_tol=1e-3))
+    assert fast.termination_status == "OPTIMAL" and fast.summary["iters"] < full.summary["iters"]
+    assert fast.summary["lambda_max"] <= 1e-6
+    opt = full.summary["objective_admm"]
+    assert fast.objective_value >= opt * (1 - 1e-4)
+    assert fast.objective_value - opt <= 2e-3 * opt
+
+
 def test_full_size_solver_invariants_w40_d20():
     """BASELINE configs[2] at full size: residuals decrease, gamma >= 0, Z symmetric and on the pattern."""
     d = helpers.load_problem("W40-D20", 0)
