@@ -163,7 +163,8 @@ struct nnsdp_solver {
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
-  DBuf<int> d_cn, d_sptr, d_stats;
+  DBuf<int> d_cn, d_sptr, d_stats, d_long;
+  int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
@@ -268,7 +269,14 @@ struct nnsdp_solver {
     }
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
-    d_stats.alloc(2); d_stats.zero();
+    d_stats.alloc(4); d_stats.zero();
+    {
+      std::vector<int> lr;
+      for (int e = 0; e < S.NE; ++e)
+        if (S.csr_ptr[e + 1] - S.csr_ptr[e] > kLongRow) lr.push_back(e);
+      nlong = (int)lr.size();
+      d_long.upload(lr);
+    }
     // M^-1 on the device (rocSOLVER potrf + potri; one-time plain-library factorisation)
     roc.reset(new RocHandle());
     RBCHK(rocblas_set_stream(roc->h, st));
@@ -336,6 +344,9 @@ struct nnsdp_solver {
     hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
     hipLaunchKernelGGL(k_spmv_A_x, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, D.csr_ptr.p, D.csr_col.p,
                        D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p);
+    if (nlong > 0)
+      hipLaunchKernelGGL(k_spmv_A_x_long, dim3(nlong), dim3(kThreads), 0, st, nlong, d_long.p, D.csr_ptr.p, D.csr_col.p, D.csr_val.p,
+                         ww.p, g.p, D.Dinv.p, x.p);
     if (check)
       hipLaunchKernelGGL(k_check_obj, dim3(cdiv(std::max(ng, NE), kThreads)), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p,
                          x.p, d_sigma(), acc.p);
@@ -688,6 +699,7 @@ struct nnsdp_solver {
       r->objective_admm = objective_admm;
     r->polish_shift = polished ? polish_shift : -1.0;
     r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
+      if (opt.verbose && stv.size() >= 4 && stv[3] > 0) std::fprintf(stderr, "[nnsdp] nontrivial rotations: %.2f %% of pair visits\n", 100.0 * stv[2] / stv[3]);
     }
   }
 

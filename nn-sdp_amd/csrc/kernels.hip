@@ -80,8 +80,9 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // rotation (c, s) that annihilates a_pq:  J = [c s; -s c],  A <- J' A J.
 // With d = aqq - app, b = 2 apq, h = hypot(d, b):  cos(2 theta) = |d|/h,  c = sqrt((1 + |d|/h)/2),
 // s = sign(d) b / (2 h c)  (the small-angle root, |theta| <= pi/4).  Two rsqrt, no divide.
-__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double thr, double& c, double& s) {
   c = 1.0; s = 0.0;
+  if (fabs(apq) <= thr) return;   // below the per-element share of the tolerance: identity
   double d = aqq - app, b = 2.0 * apq;
   double h2 = d * d + b * b;
   if (apq != 0.0 && h2 > 0.0 && h2 < 1e300) {
@@ -131,8 +132,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   const int lda = npg + 1;       // odd stride (in doubles): column walks hit distinct banks
   const int tid = threadIdx.x;
   double* A = lds;
-  double* desc = A + (size_t)npg * lda;         // 2 buffers x half pair descriptors {c, s, (p, q)} = 3 doubles each
-  double* red = desc + 3 * npg;                  // 16 doubles of reduction scratch
+  // 2 buffers x half pair descriptors {c, s, (p, q), pad} = 4 doubles each, 16-byte aligned
+  double* desc = A + (((size_t)npg * lda + 1) & ~(size_t)1);
+  double* red = desc + 4 * npg;                  // 16 doubles of reduction scratch
   int* sel = reinterpret_cast<int*>(red + 16);  // npg + 2 ints: eigen-indices on the chosen side, counters
   double* V;
   int ldv;
@@ -307,6 +309,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   // ---- Jacobi sweeps (only the lower triangle of A is read and written from here on)
   const double tolv = a.tol_dev ? *a.tol_dev : a.tol;
   const double thresh2 = tolv * tolv * fro2;  // converged when off(A) <= tol |A|_F, measured directly before each sweep
+  const double rot_thr = 0.5 * tolv * sqrt(fro2) / np;   // skipped elements together stay below tol/2
+  int nrot = 0;
   const int plane = tid - (NT - 64);            // lane index inside the parameter wave (>= 0 there)
   const int M = np - 1;                         // rounds per sweep
   // static work assignment (round independent, so the integer divisions happen once):
@@ -364,8 +368,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     if (plane >= 0 && plane < half) {
       int p = pair_top(plane, 0, M, half), q = pair_bot(plane, 0, M, half);
       double c, s;
-      jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], c, s);
-      double* dd = desc + 3 * plane;
+      jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], rot_thr, c, s);
+      nrot += (s != 0.0);
+      double* dd = desc + 4 * plane;
       dd[0] = c; dd[1] = s;
       reinterpret_cast<int*>(dd + 2)[0] = p; reinterpret_cast<int*>(dd + 2)[1] = q;
     }
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #ifdef NNSDP_STAMPS
       long long tprev = clock64();
 #endif
-      const double* dsc = desc + buf * 3 * half;
+      const double* dsc = desc + buf * 4 * half;
       // phase 1: A <- J' A J on the lower block triangle
       {
         int e00[MAXB], e01[MAXB], e10[MAXB], e11[MAXB];
@@ -385,10 +390,10 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
         for (int u = 0; u < MAXB; ++u) {
           if (blk[u] >= 0) {
             int ia = blk[u] >> 8, ib = blk[u] & 255;
-            const double* d1 = dsc + 3 * ia;
-            const double* d2 = dsc + 3 * ib;
-            r1[u] = make_double2(d1[0], d1[1]);
-            r2[u] = make_double2(d2[0], d2[1]);
+            const double* d1 = dsc + 4 * ia;
+            const double* d2 = dsc + 4 * ib;
+            r1[u] = *reinterpret_cast<const double2*>(d1);
+            r2[u] = *reinterpret_cast<const double2*>(d2);
             int2 pq1 = *reinterpret_cast<const int2*>(d1 + 2), pq2 = *reinterpret_cast<const int2*>(d2 + 2);
             e00[u] = sym_at(pq1.x, pq2.x, lda); e01[u] = sym_at(pq1.x, pq2.y, lda);
             e10[u] = sym_at(pq1.y, pq2.x, lda); e11[u] = sym_at(pq1.y, pq2.y, lda);
@@ -416,8 +421,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
         if (plane < half && r + 1 < M) {
           int p = pair_top(plane, r + 1, M, half), q = pair_bot(plane, r + 1, M, half);
           double c, s;
-          jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], c, s);
-          double* dd = desc + (buf ^ 1) * 3 * half + 3 * plane;
+          jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], rot_thr, c, s);
+          nrot += (s != 0.0);
+          double* dd = desc + (buf ^ 1) * 4 * half + 4 * plane;
           dd[0] = c; dd[1] = s;
           reinterpret_cast<int*>(dd + 2)[0] = p; reinterpret_cast<int*>(dd + 2)[1] = q;
         }
@@ -425,9 +431,10 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
           if (vunit[u] >= 0) {
-            const double* d1 = dsc + 3 * (vunit[u] >> 8);
+            const double* d1 = dsc + 4 * (vunit[u] >> 8);
             int row = vunit[u] & 255;
-            double c = d1[0], sn = d1[1];
+            double2 cs2 = *reinterpret_cast<const double2*>(d1);
+            double c = cs2.x, sn = cs2.y;
             int2 pq = *reinterpret_cast<const int2*>(d1 + 2);
             if (V_LDS || (pq.x < nv && pq.y < nv)) {       // padded index: rotation is the identity
               double* vp_ = V + (size_t)pq.x * ldv + row;
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   }
 #endif
   if (tid == 0 && a.stats) { atomicAdd(&a.stats[0], sweeps); atomicMax(&a.stats[1], sweeps); }
+  if (a.stats && plane >= 0 && plane < half) { atomicAdd(&a.stats[2], nrot); atomicAdd(&a.stats[3], sweeps * M); }
 
   // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
   if (tid == 0) {
@@ -557,7 +565,7 @@ inline hipError_t proj_allow_big_lds() {
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds) {
   int np = (nmax + 15) & ~15;
-  size_t d = (size_t)np * (np + 1) + 3 * np + 16 + (np >> 1) + 2;   // A, desc[2][half][3], red, sel[np+2] (ints)
+  size_t d = (size_t)np * (np + 1) + 1 + 4 * np + 16 + (np >> 1) + 2;   // A, desc[2][half][4], red, sel[np+2] (ints)
   if (v_lds) d += (size_t)np * (np + 1);
   return d * sizeof(double);
 }
@@ -622,6 +630,7 @@ __global__ __launch_bounds__(kThreads) void k_gemv_sym(int n, int ldm, const dou
 }
 
 // x[e] = g[e] - Dinv[e] * sum_g A[e,g] ww[g]; 16 lanes per pattern entry
+static constexpr int kLongRow = 256;   // rows of A with more nonzeros go to the block-per-row kernel
 __global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __restrict__ ptr, const int* __restrict__ col,
                                                         const double* __restrict__ val, const double* __restrict__ ww,
                                                         const double* __restrict__ g, const double* __restrict__ Dinv,
@@ -629,11 +638,25 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __rest
   int e = (blockIdx.x * kThreads + threadIdx.x) >> 4;
   int sub = threadIdx.x & 15;
   double s = 0.0;
-  if (e < NE)
+  bool mine = e < NE && ptr[e + 1] - ptr[e] <= kLongRow;
+  if (mine)
     for (int q = ptr[e] + sub; q < ptr[e + 1]; q += 16) s += val[q] * ww[col[q]];
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
-  if (e < NE && sub == 0) x[e] = g[e] - Dinv[e] * s;
+  if (mine && sub == 0) x[e] = g[e] - Dinv[e] * s;
+}
+
+// the few long rows (the affine-affine entry touches every multiplier): one workgroup per row
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_long(int nlong, const int* __restrict__ rows, const int* __restrict__ ptr,
+                                                             const int* __restrict__ col, const double* __restrict__ val,
+                                                             const double* __restrict__ ww, const double* __restrict__ g,
+                                                             const double* __restrict__ Dinv, double* __restrict__ x) {
+  __shared__ double red[8];
+  int e = rows[blockIdx.x];
+  double s = 0.0;
+  for (int q = ptr[e] + threadIdx.x; q < ptr[e + 1]; q += kThreads) s += val[q] * ww[col[q]];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) x[e] = g[e] - Dinv[e] * s;
 }
 
 // nu <- nu + alpha (K x + q - w).  acc (may be null) accumulates at check iterations:
