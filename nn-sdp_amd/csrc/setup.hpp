@@ -452,7 +452,7 @@ inline ScaledOperator scale_operator(const Operator& op, bool normalize_columns)
   std::vector<int> newgen(op.ng, -1);
   for (int g = 0; g < op.ng; ++g) {
     cn[g] = std::sqrt(cn[g]);
-    if (cn[g] > 1e-12) {
+    if (cn[g] > 1e-150) {   // only identically-zero generators are dropped; tiny-width neurons keep theirs
       newgen[g] = (int)S.keep.size();
       S.keep.push_back(g);
       S.ecol.push_back(normalize_columns ? 1.0 / cn[g] : 1.0);

@@ -64,7 +64,7 @@ def project_psd(V: np.ndarray) -> np.ndarray:
 class ScaledProblem:
     """Generator (column) normalisation + unit-norm z0 and c.  g_i = e_i * g~_i / zscale."""
 
-    def __init__(self, L: LmiOperator, drop_tol: float = 1e-12):
+    def __init__(self, L: LmiOperator, drop_tol: float = 1e-150):
         A = L.A.tocsc()
         cn = np.sqrt(np.asarray(A.multiply(A).sum(axis=0)).ravel())
         self.keep = np.nonzero(cn > drop_tol)[0]          # zero generators: gamma_i = 0
