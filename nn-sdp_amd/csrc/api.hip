@@ -75,6 +75,12 @@ static void require_gpu() {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// NNSDP_BLOCK=0/1 selects the element-wise / block (MFMA) Jacobi kernel (diagnostic override)
+static bool block_mode_requested() {
+  const char* e = std::getenv("NNSDP_BLOCK");
+  return e ? std::atoi(e) != 0 : false;
+}
+
 // device-resident operator (CSR + CSC + pattern)
 struct DevOperator {
   int NE = 0, ng = 0, n = 0;
@@ -159,7 +165,7 @@ struct nnsdp_solver {
   std::vector<long long> coff;
   long long nmat = 0;
   int ncl = 0, nmax = 0;
-  bool v_lds = true;
+  bool v_lds = true, use_block = false;
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
@@ -240,7 +246,8 @@ struct nnsdp_solver {
       throw std::invalid_argument("clique larger than 128 is not supported by the LDS-resident projection kernel");
     if (nmax > 128) throw std::invalid_argument("dense mode supports Zdim <= 128 only (use a chordal decomp_mode)");
     v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
-    lds_bytes = proj_lds_bytes(nmax, v_lds);
+    use_block = block_mode_requested() && proj_block_ok(nmax);
+    lds_bytes = proj_lds_bytes(nmax, v_lds, use_block);
     // gather sources: entry e <- (clique k, lower element (i,j))
     std::vector<int> sptr(S.NE + 1, 0);
     for (int k = 0; k < ncl; ++k) {
@@ -323,7 +330,7 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    nnsdp::launch_proj(a, ncl, nmax, v_lds, lds_bytes, st);
+    nnsdp::launch_proj(a, ncl, nmax, v_lds, lds_bytes, st, use_block);
   }
 
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
@@ -930,7 +937,8 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dE.alloc(etot);
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   bool v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
-  size_t lds = proj_lds_bytes(nmax, v_lds);
+  bool use_block = block_mode_requested() && proj_block_ok(nmax);
+  size_t lds = proj_lds_bytes(nmax, v_lds, use_block);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
@@ -938,7 +946,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
-  launch_proj(a, batch, nmax, v_lds, lds, nullptr);
+  launch_proj(a, batch, nmax, v_lds, lds, nullptr, use_block);
   HIPCHK(hipEventRecord(e1, nullptr));
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());

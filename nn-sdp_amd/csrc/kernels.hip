@@ -12,6 +12,7 @@
 //   Minv [ng x ng]             inverse of M = I + A' D^-1 A (symmetric), the Woodbury core
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace nnsdp {
 
@@ -121,7 +122,18 @@ __device__ __forceinline__ int pair_bot(int ia, int r, int M, int half) { return
 // NT = 1024 (16 waves hide the LDS latency of the rotation passes) for large blocks, 256 for small.
 // The LAST wave of the workgroup computes the next round's rotation parameters while the other
 // waves apply the current round's rotations to the eigenvectors.
-template <bool V_LDS, int NT>
+// LDS-ordered hand-off between lanes of ONE wave (DS operations of a wave execute in order; this only
+// stops the compiler from reordering them and drains the counter before dependent reads)
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// BLOCK = true: block Jacobi.  Indices are grouped in blocks of 8; a round pairs the blocks (round robin),
+// one wave diagonalises each 16x16 diagonal sub-problem in place (one cyclic sweep, rotations accumulated
+// in a 16x16 J), then A <- J'AJ and V <- VJ are applied as 16x16x16 products on v_mfma_f64_16x16x4_f64.
+// 3 workgroup barriers per block round (nb-1 block rounds per sweep) instead of 2 per element round.
+template <bool V_LDS, int NT, bool BLOCK = false>
 __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   extern __shared__ double lds[];
   const int k = blockIdx.x;
@@ -134,13 +146,15 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   double* A = lds;
   // 2 buffers x half pair descriptors {c, s, (p, q), pad} = 4 doubles each, 16-byte aligned
   double* desc = A + (((size_t)npg * lda + 1) & ~(size_t)1);
-  double* red = desc + 4 * npg;                  // 16 doubles of reduction scratch
+  double* red = desc + (BLOCK ? 0 : 4 * npg);   // block mode needs no pair descriptors                  // 16 doubles of reduction scratch
   int* sel = reinterpret_cast<int*>(red + 16);  // npg + 2 ints: eigen-indices on the chosen side, counters
   double* V;
   int ldv;
   if (V_LDS) { V = red + 16 + (npg >> 1) + 2; ldv = npg + 1; }
   else { V = a.Vg + a.coff[k]; ldv = n; }
   const double* nuk = a.nu + a.coff[k];
+  // block mode scratch: per block pair a 16x16 J (row-major) and 16 doubles of rotation parameters
+  double* Jall = V + (size_t)npg * ldv;
 
 #ifdef NNSDP_STAMPS
   long long sec_t[6]; sec_t[0] = clock64();
@@ -234,6 +248,11 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
       }
     }
     __syncthreads();
+    if (BLOCK) {   // block mode reads both triangles: mirror the lower one
+      for (int j = tid >> 6; j < npg; j += NT >> 6)
+        for (int i = (tid & 63) + j + 1; i < npg; i += 64) A[j * lda + i] = A[i * lda + j];
+      __syncthreads();
+    }
   } else if (warm) {
     // (blocks too large to keep V in LDS) A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
     //   T = A V   (written over A),   A' = V' T   (written over T)
@@ -318,7 +337,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   //    length half+1 and the rectangle ceil(half/2) x (half+1) is dealt out thread by thread
   //  * eigenvector units (pair slot, chunk of 32 rows) dealt out to 32-lane groups of all waves but the last
   constexpr int MAXB = (NT == 1024) ? 3 : 9;
-  constexpr int MAXU = 9;
+  // ceil(half * ceil(nv/32) / VG) for the sizes each variant is launched with (n <= 96 when V is in LDS)
+  constexpr int MAXU = (NT == 1024) ? (V_LDS ? 5 : 9) : 7;   // V in HBM: blocks up to n = 128
   constexpr int VG = (NT - 64) / 32;
   int blk[MAXB];
   {
@@ -357,6 +377,124 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #define STAMP(i, tprev)
 #endif
   int sweeps = 0;
+  if (BLOCK) {
+    constexpr int NW = NT / 64;
+    const int nb = npg >> 3, hb = nb >> 1, Mb = nb - 1, ntile = npg >> 4;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int lr = lane & 15, lc = lane >> 4;
+    for (;;) {
+      double off2 = 0.0;
+      for (int j = tid >> 6; j < np; j += NT >> 6)
+        for (int i = (tid & 63) + j + 1; i < np; i += 64) { double v = A[i * lda + j]; off2 += v * v; }
+      off2 = 2.0 * block_sum(off2, red);
+      if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
+      for (int br = 0; br < Mb; ++br) {
+#ifdef NNSDP_STAMPS
+        long long tprev = clock64();
+#endif
+        // ---- phase S: one wave per block pair diagonalises A[I,I] in place (one cyclic sweep), J accumulates
+        if (wv < hb) {
+          const int P = pair_top(wv, br, Mb, hb), Q = pair_bot(wv, br, Mb, hb);
+          double* Jb = Jall + (size_t)wv * 272;
+          double* ics = Jb + 256;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { int e = lane + 64 * t; Jb[e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0; }
+          auto gi = [&](int l) { return l < 8 ? 8 * P + l : 8 * Q + l - 8; };   // local 0..15 -> matrix index
+          wave_lds_sync();
+          for (int ir = 0; ir < 15; ++ir) {
+            if (lane < 8) {
+              int p = gi(pair_top(lane, ir, 15, 8)), q = gi(pair_bot(lane, ir, 15, 8));
+              double c, sn;
+              jacobi_cs(A[p * lda + p], A[q * lda + q], A[p * lda + q], rot_thr, c, sn);
+              ics[2 * lane] = c; ics[2 * lane + 1] = sn;
+            }
+            wave_lds_sync();
+            {
+              int sa = lane >> 3, sb = lane & 7;
+              int l1p = pair_top(sa, ir, 15, 8), l1q = pair_bot(sa, ir, 15, 8);
+              int l2p = pair_top(sb, ir, 15, 8), l2q = pair_bot(sb, ir, 15, 8);
+              int p1 = gi(l1p), q1 = gi(l1q), p2 = gi(l2p), q2 = gi(l2q);
+              double c1 = ics[2 * sa], s1 = ics[2 * sa + 1], c2 = ics[2 * sb], s2 = ics[2 * sb + 1];
+              double b00 = A[p1 * lda + p2], b01 = A[p1 * lda + q2], b10 = A[q1 * lda + p2], b11 = A[q1 * lda + q2];
+              double t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11;
+              double t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
+              double n00 = t00 * c2 - t01 * s2, n01 = t00 * s2 + t01 * c2;
+              double n10 = t10 * c2 - t11 * s2, n11 = t10 * s2 + t11 * c2;
+              if (sa == sb) { n01 = 0.0; n10 = 0.0; }
+              A[p1 * lda + p2] = n00; A[p1 * lda + q2] = n01; A[q1 * lda + p2] = n10; A[q1 * lda + q2] = n11;
+              // J <- J R : (row, slot) items, 2 per lane
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                int it = lane + 64 * t;
+                int row = it & 15, sl = it >> 4;
+                int jp = pair_top(sl, ir, 15, 8), jq = pair_bot(sl, ir, 15, 8);
+                double c = ics[2 * sl], sn = ics[2 * sl + 1];
+                double xp = Jb[row * 16 + jp], xq = Jb[row * 16 + jq];
+                Jb[row * 16 + jp] = c * xp - sn * xq;
+                Jb[row * 16 + jq] = sn * xp + c * xq;
+              }
+            }
+            wave_lds_sync();
+          }
+        }
+        STAMP(0, tprev)
+        __syncthreads();
+        STAMP(1, tprev)
+        // ---- phase U1: A[:, I] <- A[:, I] J (rows outside I) and V[:, I] <- V[:, I] J, one 16-row tile per task
+        for (int task = wv; task < 2 * hb * ntile; task += NW) {
+          const bool isV = task >= hb * ntile;
+          int tt = isV ? task - hb * ntile : task;
+          int pi = tt / ntile, tile = tt - pi * ntile;
+          const int P = pair_top(pi, br, Mb, hb), Q = pair_bot(pi, br, Mb, hb);
+          const double* Jb = Jall + (size_t)pi * 272;
+          const int r0 = 16 * tile;
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            int kl = 4 * kk + lc;
+            int kg = kl < 8 ? 8 * P + kl : 8 * Q + kl - 8;
+            double av = isV ? V[(r0 + lr) + (size_t)kg * ldv] : A[(r0 + lr) * lda + kg];
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Jb[kl * 16 + lr], c, 0, 0, 0);
+          }
+          int cg = lr < 8 ? 8 * P + lr : 8 * Q + lr - 8;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int row = r0 + lc + 4 * r;
+            if (isV) V[row + (size_t)cg * ldv] = c[r];
+            else if ((row >> 3) != P && (row >> 3) != Q) A[row * lda + cg] = c[r];
+          }
+        }
+        __syncthreads();
+        STAMP(2, tprev)
+        // ---- phase U2: A[I, :] <- J' A[I, :] (columns outside I), one 16-column tile per task
+        for (int task = wv; task < hb * ntile; task += NW) {
+          int pi = task / ntile, tile = task - pi * ntile;
+          const int P = pair_top(pi, br, Mb, hb), Q = pair_bot(pi, br, Mb, hb);
+          const double* Jb = Jall + (size_t)pi * 272;
+          const int c0 = 16 * tile;
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            int kl = 4 * kk + lc;
+            int kg = kl < 8 ? 8 * P + kl : 8 * Q + kl - 8;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(Jb[kl * 16 + lr], A[kg * lda + c0 + lr], c, 0, 0, 0);
+          }
+          int col = c0 + lr;
+          if ((col >> 3) != P && (col >> 3) != Q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int il = lc + 4 * r;
+              int ig = il < 8 ? 8 * P + il : 8 * Q + il - 8;
+              A[ig * lda + col] = c[r];
+            }
+          }
+        }
+        __syncthreads();
+        STAMP(3, tprev)
+      }
+      ++sweeps;
+    }
+  } else {
   for (;;) {
     // direct measurement of off(A)^2 (no cancellation): ~1/40 of a sweep
     double off2 = 0.0;
@@ -428,20 +566,22 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
           reinterpret_cast<int*>(dd + 2)[0] = p; reinterpret_cast<int*>(dd + 2)[1] = q;
         }
       } else {
+        {
 #pragma unroll
-        for (int u = 0; u < MAXU; ++u) {
-          if (vunit[u] >= 0) {
-            const double* d1 = dsc + 4 * (vunit[u] >> 8);
-            int row = vunit[u] & 255;
-            double2 cs2 = *reinterpret_cast<const double2*>(d1);
-            double c = cs2.x, sn = cs2.y;
-            int2 pq = *reinterpret_cast<const int2*>(d1 + 2);
-            if (V_LDS || (pq.x < nv && pq.y < nv)) {       // padded index: rotation is the identity
-              double* vp_ = V + (size_t)pq.x * ldv + row;
-              double* vq_ = V + (size_t)pq.y * ldv + row;
-              double xp = *vp_, xq = *vq_;
-              *vp_ = c * xp - sn * xq;
-              *vq_ = sn * xp + c * xq;
+          for (int u = 0; u < MAXU; ++u) {
+            if (vunit[u] >= 0) {
+              const double* d1 = dsc + 4 * (vunit[u] >> 8);
+              int row = vunit[u] & 255;
+              double2 cs2 = *reinterpret_cast<const double2*>(d1);
+              double c = cs2.x, sn = cs2.y;
+              int2 pq = *reinterpret_cast<const int2*>(d1 + 2);
+              if (V_LDS || (pq.x < nv && pq.y < nv)) {       // padded index: rotation is the identity
+                double* vp_ = V + (size_t)pq.x * ldv + row;
+                double* vq_ = V + (size_t)pq.y * ldv + row;
+                double xp = *vp_, xq = *vq_;
+                *vp_ = c * xp - sn * xq;
+                *vq_ = sn * xp + c * xq;
+              }
             }
           }
         }
@@ -452,6 +592,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
       buf ^= 1;
     }
     ++sweeps;
+  }
   }
 #ifdef NNSDP_STAMPS
   sec_t[3] = clock64();
@@ -543,7 +684,12 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 
 // launch: NT = 1024 for blocks above kSmallBlock, 256 below
 static constexpr int kSmallBlock = 40;
-inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st) {
+inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, bool block = false) {
+  if (block && v_lds) {
+    if (nmax > kSmallBlock) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, true>), dim3(nblocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_proj_jacobi<true, 256, true>), dim3(nblocks), dim3(256), lds, st, a);
+    return;
+  }
   if (nmax > kSmallBlock) {
     if (v_lds) hipLaunchKernelGGL((k_proj_jacobi<true, 1024>), dim3(nblocks), dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((k_proj_jacobi<false, 1024>), dim3(nblocks), dim3(1024), lds, st, a);
@@ -554,6 +700,10 @@ inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, si
 }
 inline hipError_t proj_allow_big_lds() {
   hipError_t e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -563,12 +713,16 @@ inline hipError_t proj_allow_big_lds() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-inline size_t proj_lds_bytes(int nmax, bool v_lds) {
+inline size_t proj_lds_bytes(int nmax, bool v_lds, bool block = false) {
   int np = (nmax + 15) & ~15;
-  size_t d = (size_t)np * (np + 1) + 1 + 4 * np + 16 + (np >> 1) + 2;   // A, desc[2][half][4], red, sel[np+2] (ints)
+  size_t d = (size_t)np * (np + 1) + 1 + 16 + (np >> 1) + 2;           // A, red, sel[np+2] (ints)
   if (v_lds) d += (size_t)np * (np + 1);
+  if (block) d += (size_t)(np >> 4) * 272;                             // J + rotation parameters per block pair
+  else d += 4 * (size_t)np;                                            // desc[2][half][4]
   return d * sizeof(double);
 }
+// block mode needs V in LDS and its scratch next to it
+inline bool proj_block_ok(int nmax) { return proj_lds_bytes(nmax, true, true) <= 160 * 1024; }
 
 // ---------------------------------------------------------------------------------------------
 // multiplier block: w_s = max(nu_s, 0), reflection p = 2 w_s - nu_s - c   (also applies kappa)

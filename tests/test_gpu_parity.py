@@ -79,6 +79,23 @@ def test_projection_properties_at_full_size():
         assert np.linalg.eigvalsh(P[7]).min() >= -1e-10
 
 
+def test_block_jacobi_variant_matches_lapack(monkeypatch):
+    """NNSDP_BLOCK=1 selects the experimental block-Jacobi kernel (16x16 rotation blocks applied with
+    v_mfma_f64_16x16x4_f64).  Same answers; it is not the default because it measured 2.3x slower per sweep
+    (DESIGN.md section 4)."""
+    monkeypatch.setenv("NNSDP_BLOCK", "1")
+    rng = np.random.default_rng(3)
+    mats = [_sym(rng, n) for n in (5, 16, 31, 40, 64, 85, 96)]
+    res, evs, _ = na.project_psd_batched(mats)
+    for A, P, ev in zip(mats, res, evs):
+        assert np.abs(P - _ref_proj(A)).max() <= 1e-10 * max(1.0, np.abs(A).max())
+        assert np.abs(np.sort(ev) - np.linalg.eigvalsh(A)).max() <= 1e-10 * max(1.0, np.abs(A).max())
+    d = helpers.load_problem("W10-D5", 0)
+    s = na.runQuery(helpers.product_query(d), na.AdmmSdpOptions(max_iters=1500, proj_tol=1e-12, polish=False))
+    r = _oracle_solve(d, "single", 1500)
+    assert abs(s.objective_value - r.objective) <= 1e-6 * abs(r.objective)
+
+
 # ----------------------------------------------------------------------------- K1 / K2: assembly and adjoint
 @pytest.mark.parametrize("name,beta", [("W10-D5", 0), ("W10-D5", 3), ("W10-D10", 2)])
 def test_makeZ_and_adjoint_match_golden(name, beta):

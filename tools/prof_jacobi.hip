@@ -18,7 +18,8 @@ int main(int argc, char** argv) {
   hipMalloc(&dnu, h.size() * 8); hipMalloc(&dw, h.size() * 8); hipMalloc(&dV, h.size() * 8); hipMalloc(&dE, (8192 + batch * n) * 8);
   hipMemcpy(dcn, cn.data(), batch * 4, hipMemcpyHostToDevice); hipMemcpy(dco, coff.data(), (batch + 1) * 8, hipMemcpyHostToDevice);
   hipMemcpy(deo, eoff.data(), (batch + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(dnu, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-  bool v_lds = proj_lds_bytes(n, true) <= 160 * 1024; size_t lds = proj_lds_bytes(n, v_lds);
+  bool blockmode = argc > 5 && atoi(argv[5]) && proj_block_ok(n);
+  bool v_lds = proj_lds_bytes(n, true) <= 160 * 1024; size_t lds = proj_lds_bytes(n, v_lds, blockmode);
   proj_allow_big_lds();
   ProjArgs a; a.cn = dcn; a.coff = dco; a.eoff = deo; a.nu = dnu; a.w = dw; a.Vg = dV; a.eig = dE; a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -30,7 +31,7 @@ int main(int argc, char** argv) {
       hipMemcpy(dnu, h.data(), h.size() * 8, hipMemcpyHostToDevice);
       a.warm = 1; a.tol = argc > 4 ? atof(argv[4]) : 1e-6;
     }
-    hipEventRecord(e0); launch_proj(a, batch, n, v_lds, lds, nullptr); hipEventRecord(e1); hipDeviceSynchronize();
+    hipEventRecord(e0); launch_proj(a, batch, n, v_lds, lds, nullptr, blockmode); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long dbg[70]; hipMemcpy(dbg, dE + 4096, sizeof(dbg), hipMemcpyDeviceToHost);
     printf("n=%d batch=%d v_lds=%d kernel %.3f ms sweeps %lld -> %.1f us/sweep\n", n, batch, (int)v_lds, ms, dbg[64], 1e3 * ms / dbg[64]);
@@ -38,7 +39,7 @@ int main(int argc, char** argv) {
     printf("  sections (cycles, wave 0): load+basis %lld  warm-GEMM %lld  sweeps %lld  reconstruct+store %lld\n", dbg[65], dbg[66], dbg[67], dbg[69]);
     if (rep != 1 && rep != 3) continue;
     int nw = n > kSmallBlock ? 16 : 4;
-    long long rounds = dbg[64] * (((n + 1) & ~1) - 1);
+    long long rounds = blockmode ? dbg[64] * ((((n + 15) & ~15) >> 3) - 1) : dbg[64] * (((n + 1) & ~1) - 1);
     for (int w = 0; w < nw; ++w) printf("  wave %2d cycles/round: phase1 %6.0f barrier %6.0f phase2 %6.0f barrier %6.0f\n", w,
       (double)dbg[w*4]/rounds, (double)dbg[w*4+1]/rounds, (double)dbg[w*4+2]/rounds, (double)dbg[w*4+3]/rounds);
 #endif
