@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--beta", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=8, help="independent SDPs solved side by side in the batched leg (0/1 = skip)")
     ap.add_argument("--cert-seconds", type=float, default=30.0, help="time cap of the time-to-certificate solve (0 = skip)")
     args = ap.parse_args()
 
@@ -181,6 +182,20 @@ def main():
                                       "certified_gap_1e-3: stop as soon as the polished (exactly feasible) objective is within 1e-3 of the "
                                       "ADMM primal/dual estimates. rho = objective of the polished point; lambda_max = eigmax(Z(gamma)) "
                                       "in the reference's coordinates (reference acceptance: 1e-6 .. 1e-4)")
+    if rank == 0 and world == 1 and args.batch > 1:
+        # the same kernels with `batch` independent SDPs side by side on one GPU (one HIP stream each)
+        sb = na.SolverBatch([q] * args.batch, opts)
+        sb.iterate(args.warmup)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        sb.iterate(args.steps)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        sb.close()
+        agg = args.batch * args.steps / tb
+        out["batched"] = {"sdps": args.batch, "aggregate_iters_per_s": agg, "per_sdp_iters_per_s": agg / args.batch,
+                          "eig_TFLOPs_if_same_share": agg * float(sm["eig_flops_per_iter"]) / 1e12,
+                          "note": "independent SDPs (e.g. the beta = 0..7 sweep of experiments/scale.jl:28) on one GPU, hipGraph replay per handle"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds)
     elif rank == 0:

@@ -132,6 +132,11 @@ int nnsdp_solver_create(const nnsdp_problem* p, const nnsdp_options* o, nnsdp_so
 /* run `iters` ADMM iterations (no convergence test); eig_ms (may be NULL) receives the HIP-event
  * time of the projection kernel summed over these iterations. */
 int nnsdp_solver_iterate(nnsdp_solver* s, int32_t iters, double* eig_ms);
+/* enqueue `iters` iterations on the solver's own HIP stream without waiting: several handles (independent
+ * SDPs: the beta sweep of experiments/scale.jl:28, the hyperplanes of NnSdp.findReach2Dpoly) then run
+ * concurrently on one GPU; nnsdp_solver_sync waits for one handle. */
+int nnsdp_solver_iterate_async(nnsdp_solver* s, int32_t iters);
+int nnsdp_solver_sync(nnsdp_solver* s);
 /* relative residuals and objectives of the current iterate */
 int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* pobj, double* dobj);
 /* iterate until converged / limits; fills r like nnsdp_solve */

@@ -386,7 +386,7 @@ struct nnsdp_solver {
   }
 
   // run n plain iterations; timed=true launches eagerly with HIP events around the projection kernel
-  void iterate(int n, double* eig_ms) {
+  void iterate(int n, double* eig_ms, bool sync = true) {
     if (n <= 0) return;
     if (eig_ms) {
       while ((int)ev.size() < 2 * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
@@ -411,7 +411,7 @@ struct nnsdp_solver {
         ++iters_done; --left;
       }
     }
-    HIPCHK(hipStreamSynchronize(st));
+    if (sync) HIPCHK(hipStreamSynchronize(st));
   }
 
   // one iteration with residual accumulation; fills last_*
@@ -811,6 +811,21 @@ int nnsdp_solver_iterate(nnsdp_solver* s, int32_t iters, double* eig_ms) {
   double t0 = now_s();
   s->iterate(iters, eig_ms);
   s->t_solve += now_s() - t0;
+  API_END
+}
+
+int nnsdp_solver_iterate_async(nnsdp_solver* s, int32_t iters) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  if (iters < 0) throw std::invalid_argument("iters must be >= 0");
+  s->iterate(iters, nullptr, false);
+  API_END
+}
+
+int nnsdp_solver_sync(nnsdp_solver* s) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  HIPCHK(hipStreamSynchronize(s->st));
   API_END
 }
 

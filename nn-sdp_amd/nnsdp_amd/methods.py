@@ -357,6 +357,12 @@ class Solver:
         _lib.check(self.lib.nnsdp_solver_iterate(self.h, int(iters), C.byref(ms) if time_eig else None))
         return ms.value
 
+    def iterate_async(self, iters: int) -> None:
+        _lib.check(self.lib.nnsdp_solver_iterate_async(self.h, int(iters)))
+
+    def sync(self) -> None:
+        _lib.check(self.lib.nnsdp_solver_sync(self.h))
+
     def residuals(self):
         a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         _lib.check(self.lib.nnsdp_solver_residuals(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
@@ -382,6 +388,35 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+
+class SolverBatch:
+    """Independent SDPs solved side by side on one GPU (one HIP stream each): the beta sweep of
+    experiments/scale.jl:28 or the hyperplane directions of NnSdp.findReach2Dpoly (src/NnSdp.jl:73-95).
+    A single W40-D20 SDP occupies 19 of the 256 CUs; a batch fills the chip with the same kernels."""
+
+    def __init__(self, queries, opts: AdmmSdpOptions):
+        self.solvers = [Solver(q, opts) for q in queries]
+
+    def iterate(self, iters: int, chunk: int = 64) -> None:
+        done = 0
+        while done < iters:
+            n = min(chunk, iters - done)
+            for s in self.solvers:
+                s.iterate_async(n)
+            done += n
+        for s in self.solvers:
+            s.sync()
+
+    def residuals(self):
+        return [s.residuals() for s in self.solvers]
+
+    def finish(self):
+        return [s.finish() for s in self.solvers]
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
 
 
 def makeZ(query, gamma) -> np.ndarray:

@@ -347,6 +347,24 @@ def test_acas_shaped_safety_query_tracks_oracle():
     assert np.abs(s.values["Z"] - Zo).max() <= 1e-9 * max(1.0, np.abs(Zo).max())
 
 
+def test_solver_batch_matches_single_solves():
+    """independent SDPs side by side on one GPU (SolverBatch, one HIP stream per handle) give exactly the
+    iterates of the same problems solved one after the other."""
+    ds = [helpers.load_problem("W10-D5", 0), helpers.load_problem("W10-D5", 3), helpers.load_problem("W10-D10", 0)]
+    qs = [helpers.product_query(d) for d in ds]
+    opts = na.AdmmSdpOptions(max_iters=10 ** 8, proj_tol=1e-12)
+    sb = na.SolverBatch(qs, opts)
+    sb.iterate(300)
+    rb = sb.residuals()
+    sb.close()
+    for q, r in zip(qs, rb):
+        sv = na.Solver(q, opts)
+        sv.iterate(300)
+        r1 = sv.residuals()
+        sv.close()
+        assert np.allclose(r, r1, rtol=1e-9, atol=1e-14)
+
+
 def test_solver_argument_errors():
     d = helpers.load_problem("W10-D5", 0)
     q = helpers.product_query(d)
