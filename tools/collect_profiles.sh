@@ -40,4 +40,5 @@ if k:
     print("k_proj_jacobi per launch: FETCH_SIZE KB", f, "WRITE_SIZE KB", w, "LDS conflict share",
           k.get("SQ_LDS_BANK_CONFLICT", {}).get("mean_per_launch", 0) / max(k.get("SQ_LDS_IDX_ACTIVE", {}).get("mean_per_launch", 1), 1))
 PY
+rm -rf $OUT/stats $OUT/pmc_*   # raw traces are large; only the aggregates travel back
 head -4 $OUT/${TAG}_bench_W40-D20_kernel_stats.csv | cut -c1-160
