@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import nnet_io, qc, operator as op  # noqa: E402
 
-NETS = ["W10-D5", "W10-D10", "W10-D20", "W20-D10", "W40-D20", "W40-D40"]
+NETS = ["W10-D5", "W10-D10", "W10-D20", "W10-D30", "W10-D50", "W10-D60", "W20-D10", "W20-D20", "W20-D30", "W20-D50",
+        "W40-D20", "W40-D40"]
 PROBLEMS = [("W10-D5", 0), ("W10-D5", 3), ("W10-D10", 0), ("W10-D10", 2), ("W10-D20", 0), ("W20-D10", 0),
             ("W40-D20", 0), ("W40-D20", 2), ("W40-D40", 0)]
 GOLDEN = [("W10-D5", 0), ("W10-D5", 3), ("W10-D10", 2)]
