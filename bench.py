@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--beta", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
+                    help="N > 1: replica = one independent SDP per GPU, no data-path collective (weak scaling, default); "
+                         "shard = ONE SDP, cliques sharded over the GPUs, RCCL all-reduce of the consensus sum per iteration (strong)")
     ap.add_argument("--batch", type=int, default=8, help="independent SDPs solved side by side in the batched leg (0/1 = skip)")
     ap.add_argument("--cert-seconds", type=float, default=30.0, help="time cap of the time-to-certificate solve (0 = skip)")
     args = ap.parse_args()
@@ -96,6 +99,14 @@ def main():
     q = helpers.product_query(d)
     opts = na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9, device=local_rank)
     solver = na.Solver(q, opts)           # setup: pattern, generators, factorisation; everything now in HBM
+    shard = args.mode == "shard"
+    if shard:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(na.comm_unique_id()), dtype=torch.uint8).cuda()
+        if dist is not None:
+            dist.broadcast(uid, src=0)
+        solver.set_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
     solver.iterate(args.warmup, time_eig=True)
 
     def barrier():
@@ -119,7 +130,7 @@ def main():
 
     # hipGraph replay rate of the same iteration (what nnsdp_solve itself uses)
     tg0 = time.perf_counter()
-    solver.iterate(args.steps)
+    solver.iterate(args.steps)          # every rank runs this too (sharded mode: collective inside)
     torch.cuda.synchronize()
     graph_ips = args.steps / (time.perf_counter() - tg0)
     solver.close()
@@ -142,19 +153,20 @@ def main():
         ach_tf = flops / eig_avg_s / 1e12
         out = {
             "metric": "ADMM iters/sec + wall-clock to eps-cert, bench/rand W=40 D=20",
-            "value": world * args.steps / dt,
+            "value": (1 if shard else world) * args.steps / dt,
             "unit": "ADMM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "reference bench/rand random network (fixture), CROWN-sliced intervals and sampled ellipsoid precomputed on the host",
             "config": {"workload": f"bench/rand scale-I2-O2-{args.workload} beta={args.beta}, findEllipsoid on [0.5,1.5]^2, "
                                    f"chordal SingleDecomp, {sm['n_cliques']} PSD blocks (max n={sm['max_clique']}) on 1 GPU"
-                                   + ("" if world == 1 else f"; {world} independent SDPs, one per GPU"),
-                       "parallelism": "1 SDP per GPU, cliques batched in one launch"},
+                                   + ("" if world == 1 else (f"; ONE SDP, cliques sharded over {world} GPUs, RCCL all-reduce per iteration" if shard
+                                                             else f"; {world} independent SDPs, one per GPU")),
+                       "parallelism": ("clique-sharded, 1 all-reduce/iteration" if shard else "1 SDP per GPU, cliques batched in one launch")},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "k_proj_jacobi", "kernel_avg_us": eig_avg_s * 1e6,
@@ -164,7 +176,7 @@ def main():
             "graph_replay_iters_per_s": graph_ips,
             "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
         }
-    if rank == 0 and world == 1 and args.cert_seconds > 0:
+    if rank == 0 and world == 1 and args.cert_seconds > 0 and not shard:
         # wall-clock to certificate on fresh solves (setup + ADMM to eps_rel = 1e-6 + feasibility polish)
         out["time_to_cert"] = {}
         for mode in (na.SingleDecomp(), na.DoubleDecomp()):
@@ -182,7 +194,7 @@ def main():
                                       "certified_gap_1e-3: stop as soon as the polished (exactly feasible) objective is within 1e-3 of the "
                                       "ADMM primal/dual estimates. rho = objective of the polished point; lambda_max = eigmax(Z(gamma)) "
                                       "in the reference's coordinates (reference acceptance: 1e-6 .. 1e-4)")
-    if rank == 0 and world == 1 and args.batch > 1:
+    if rank == 0 and world == 1 and args.batch > 1 and not shard:
         # the same kernels with `batch` independent SDPs side by side on one GPU (one HIP stream each)
         sb = na.SolverBatch([q] * args.batch, opts)
         sb.iterate(args.warmup)

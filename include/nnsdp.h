@@ -166,8 +166,12 @@ int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t de
 int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mats, double* out,
                               double* eigvals, double* kernel_ms);
 
-/* Multi-GPU (clique-sharded) mode: RCCL communicator over the ranks of one node.  The unique id
- * is produced on rank 0 and distributed by the host launcher (torch.distributed in bench.py). */
+/* Multi-GPU clique-sharded mode (one SDP over several GPUs of one node): every rank creates the same solver,
+ * then nnsdp_solver_set_comm() before the first iteration.  Rank r projects a contiguous range of cliques
+ * (balanced by n_k^3); the consensus sum sum_k H_k'(2 w_k - nu_k) is exchanged with ONE ncclAllReduce (RCCL
+ * over xGMI) per iteration, everything else is replicated.  The 128-byte unique id is produced on rank 0
+ * and distributed by the host launcher (torch.distributed in bench.py --mode shard).  RCCL is dlopen'ed on
+ * first use.  Independent SDPs need none of this (bench.py default, nnsdp_amd/parallel.py). */
 int nnsdp_comm_unique_id(char* id128);
 int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const char* id128);
 

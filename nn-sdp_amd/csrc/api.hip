@@ -5,6 +5,8 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdio>
 #include <memory>
@@ -127,6 +129,37 @@ struct FullOperator {
   }
 };
 
+// RCCL is loaded lazily (dlopen) and only in clique-sharded mode, so the default single-GPU / replica paths
+// never touch it.  Minimal declarations matching /opt/rocm/include/rccl/rccl.h.
+struct Rccl {
+  struct UniqueId { char internal[128]; };
+  typedef void* Comm;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  static constexpr int kFloat64 = 8, kSum = 0;
+  static Rccl& get() {
+    static Rccl r;
+    if (!r.GetUniqueId) {
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+      if (!h) throw HipError(std::string("cannot load RCCL: ") + dlerror());
+      auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) throw HipError(std::string("RCCL symbol missing: ") + n); return p; };
+      r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+      r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+      r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+      r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+      r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    }
+    return r;
+  }
+  void check(int rc, const char* what) {
+    if (rc != 0) throw HipError(std::string(what) + " failed: " + (GetErrorString ? GetErrorString(rc) : "?"));
+  }
+};
+
 struct RocHandle {
   rocblas_handle h = nullptr;
   RocHandle() { RBCHK(rocblas_create_handle(&h)); }
@@ -188,8 +221,15 @@ struct nnsdp_solver {
   double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
   double last_pres = 1e300, last_dres = 1e300, last_pobj = 0, last_dobj = 0;
   std::unique_ptr<FullOperator> full;
+  // clique-sharded mode (one rank per GPU, RCCL all-reduce of the consensus sum per iteration)
+  int nranks = 1, rank = 0, k0 = 0, k1 = 0;
+  Rccl::Comm comm = nullptr;
+  DBuf<int> d_sptr_own;
+  DBuf<long long> d_soff_own;
+  DBuf<double> hsum;
 
   ~nnsdp_solver() {
+    if (comm) (void)Rccl::get().CommDestroy(comm);
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -319,18 +359,61 @@ struct nnsdp_solver {
     double sc[4] = {sigma, 1.0, proj_tol, 0.0};
     HIPCHK(hipMemcpy(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice));
     if (lds_bytes > 64 * 1024) HIPCHK(proj_allow_big_lds());
+    k0 = 0; k1 = ncl;
     t_setup = now_s() - t_create0;
+  }
+
+  void set_comm(int nr, int rk, const char* id128) {
+    if (nr < 1 || rk < 0 || rk >= nr || !id128) throw std::invalid_argument("bad communicator arguments");
+    if (iters_done != 0) throw std::invalid_argument("set_comm must be called before the first iteration");
+    Rccl& R = Rccl::get();
+    Rccl::UniqueId uid;
+    std::memcpy(uid.internal, id128, 128);
+    R.check(R.CommInitRank(&comm, nr, uid, rk), "ncclCommInitRank");
+    nranks = nr; rank = rk;
+    // contiguous clique ranges balanced by n_k^3 (cliques k, k+1 overlap, so neighbours stay together)
+    std::vector<double> cost(ncl);
+    double tot = 0;
+    for (int k = 0; k < ncl; ++k) { cost[k] = (double)cn[k] * cn[k] * cn[k]; tot += cost[k]; }
+    std::vector<int> start(nr + 1, ncl);
+    start[0] = 0;
+    double accum = 0;
+    int r = 1;
+    for (int k = 0; k < ncl && r < nr; ++k) {
+      accum += cost[k];
+      if (accum >= tot * r / nr) start[r++] = k + 1;
+    }
+    for (; r < nr; ++r) start[r] = ncl;
+    k0 = start[rk]; k1 = start[rk + 1];
+    // source lists restricted to the owned cliques
+    std::vector<int> sp = d_sptr.download();
+    std::vector<long long> so = d_soff.download();
+    std::vector<int> sp2(S.NE + 1, 0);
+    std::vector<long long> so2;
+    for (int e = 0; e < S.NE; ++e) {
+      for (int q = sp[e]; q < sp[e + 1]; ++q)
+        if (so[q] >= coff[k0] && so[q] < coff[k1]) so2.push_back(so[q]);
+      sp2[e + 1] = (int)so2.size();
+    }
+    if (so2.empty()) so2.push_back(0);
+    d_sptr_own.upload(sp2); d_soff_own.upload(so2);
+    hsum.alloc(S.NE);
+  }
+
+  void allreduce(double* buf, size_t count) {
+    Rccl& R = Rccl::get();
+    R.check(R.AllReduce(buf, buf, count, Rccl::kFloat64, Rccl::kSum, comm, st), "ncclAllReduce");
   }
 
   void enqueue_proj(bool warm) {
     ProjArgs a;
-    a.cn = d_cn.p; a.coff = d_coff.p; a.eoff = nullptr;
+    a.cn = d_cn.p + k0; a.coff = d_coff.p + k0; a.eoff = nullptr;
     a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr;
     a.kappa = d_kappa(); a.tol_dev = scal.p + 2; a.stats = d_stats.p;
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    nnsdp::launch_proj(a, ncl, nmax, v_lds, lds_bytes, st, use_block);
+    if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, use_block);
   }
 
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
@@ -339,14 +422,27 @@ struct nnsdp_solver {
     if (e0) HIPCHK(hipEventRecord(e0, st));
     enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
-    hipLaunchKernelGGL(k_gather_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
-                       nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p);
+    if (comm) {
+      hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
+                         nu.p + ng, w.p + ng, 0, hsum.p);
+      allreduce(hsum.p, NE);                      // the overlap-consensus exchange: one all-reduce per iteration
+      hipLaunchKernelGGL(k_finish_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, hsum.p, D.z0.p, D.Dinv.p, d_sigma(), g.p);
+    } else {
+      hipLaunchKernelGGL(k_gather_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
+                         nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p);
+    }
     hipLaunchKernelGGL(k_spmv_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, D.csc_ptr.p, D.csc_row.p,
                        D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
     if (check) {
       HIPCHK(hipMemsetAsync(acc.p, 0, 8 * sizeof(double), st));
+      if (comm) {
+        hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
+                           nu.p + ng, w.p + ng, 1, hsum.p);
+        allreduce(hsum.p, NE);
+      }
       hipLaunchKernelGGL(k_check_dual, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, ng, D.csr_ptr.p,
-                         D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p);
+                         D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p,
+                         comm ? hsum.p : (const double*)nullptr);
     }
     hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
     hipLaunchKernelGGL(k_spmv_A_x, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, D.csr_ptr.p, D.csr_col.p,
@@ -358,7 +454,9 @@ struct nnsdp_solver {
       hipLaunchKernelGGL(k_check_obj, dim3(cdiv(std::max(ng, NE), kThreads)), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p,
                          x.p, d_sigma(), acc.p);
     hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
-                       d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr);
+                       d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr, coff[k0], coff[k1],
+                       (!comm || rank == 0) ? 1 : 0);
+    if (check && comm) allreduce(acc.p, 3);       // residual sums of the clique blocks live on their owners
     HIPCHK(hipGetLastError());
   }
 
@@ -402,7 +500,7 @@ struct nnsdp_solver {
     int left = n;
     while (left > 0) {
       bool can_warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
-      if (can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
+      if (!comm && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
         build_graph(kGraphIters);
         HIPCHK(hipGraphLaunch(gexec, st));
         since_cold += kGraphIters; iters_done += kGraphIters; left -= kGraphIters;
@@ -975,15 +1073,21 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
 }
 
 int nnsdp_comm_unique_id(char* id128) {
-  (void)id128;
-  g_err = "clique-sharded multi-GPU mode is not built in this version (bench.py --gpus N runs independent SDPs per rank)";
-  return 1;
+  API_BEGIN
+  if (!id128) throw std::invalid_argument("null argument");
+  require_gpu();
+  Rccl& R = Rccl::get();
+  Rccl::UniqueId uid;
+  R.check(R.GetUniqueId(&uid), "ncclGetUniqueId");
+  std::memcpy(id128, uid.internal, 128);
+  API_END
 }
 
 int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const char* id128) {
-  (void)s; (void)nranks; (void)rank; (void)id128;
-  g_err = "clique-sharded multi-GPU mode is not built in this version (bench.py --gpus N runs independent SDPs per rank)";
-  return 1;
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  s->set_comm(nranks, rank, id128);
+  API_END
 }
 
 }  // extern "C"

@@ -763,6 +763,29 @@ __global__ __launch_bounds__(kThreads) void k_gather_g(int NE, const int* __rest
   g[e] = Dinv[e] * (z0[e] / (*sigma) + s);
 }
 
+// clique-sharded mode: h[e] = wgt * sum over the rank's OWN sources of (2 w - nu), or of (nu - w) when dual != 0;
+// summed over ranks with one all-reduce, then k_finish_g
+__global__ __launch_bounds__(kThreads) void k_gather_h(int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
+                                                        const unsigned char* __restrict__ isdiag, const double* __restrict__ nuk,
+                                                        const double* __restrict__ wk, int dual, double* __restrict__ h) {
+  int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= NE) return;
+  double s = 0.0;
+  for (int q = sptr[e]; q < sptr[e + 1]; ++q) {
+    long long o = soff[q];
+    s += dual ? nuk[o] - wk[o] : 2.0 * wk[o] - nuk[o];
+  }
+  if (!isdiag[e]) s *= kSqrt2;
+  h[e] = s;
+}
+
+__global__ __launch_bounds__(kThreads) void k_finish_g(int NE, const double* __restrict__ h, const double* __restrict__ z0,
+                                                        const double* __restrict__ Dinv, const double* __restrict__ sigma,
+                                                        double* __restrict__ g) {
+  int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e < NE) g[e] = Dinv[e] * (z0[e] / (*sigma) + h[e]);
+}
+
 // ww = Minv qv  (Minv symmetric, column-major): one wave per output row, coalesced column reads
 __global__ __launch_bounds__(kThreads) void k_gemv_sym(int n, int ldm, const double* __restrict__ Minv, const double* __restrict__ x,
                                                         double* __restrict__ y) {
@@ -819,7 +842,10 @@ __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, 
                                                          const double* __restrict__ ww, const double* __restrict__ c,
                                                          const double* __restrict__ x, const unsigned int* __restrict__ gidx,
                                                          double* __restrict__ nu, const double* __restrict__ w,
-                                                         double alpha, double* __restrict__ kappa, double* __restrict__ acc) {
+                                                         double alpha, double* __restrict__ kappa, double* __restrict__ acc,
+                                                         long long lo, long long hi, int acc_s) {
+  // [lo, hi): the clique elements this rank owns (everything when not sharded); acc_s: count the
+  // multiplier block in the residual sums (rank 0 only when sharded, the sums are all-reduced)
   __shared__ double red[8];
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   double r2 = 0.0, k2 = 0.0, w2 = 0.0;
@@ -828,8 +854,8 @@ __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, 
     double kxq = p[i] + ww[i] + c[i];
     double res = kxq - wv;
     nu[i] = v + alpha * res;
-    r2 = res * res; k2 = kxq * kxq; w2 = wv * wv;
-  } else if (i < ng + nmat) {
+    if (acc_s) { r2 = res * res; k2 = kxq * kxq; w2 = wv * wv; }
+  } else if (i < ng + nmat && i - ng >= lo && i - ng < hi) {
     long long m = i - ng;
     unsigned int gi = gidx[m];
     double xv = x[gi & 0x7fffffffu];
@@ -855,7 +881,8 @@ __global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, const i
                                                           const long long* __restrict__ soff, const unsigned char* __restrict__ isdiag,
                                                           const double* __restrict__ nu, const double* __restrict__ w,
                                                           const double* __restrict__ z0, const double* __restrict__ sigma,
-                                                          double* __restrict__ acc) {
+                                                          double* __restrict__ acc, const double* __restrict__ hsum) {
+  // hsum != null (clique-sharded mode): the clique part of K'y/sigma, already summed over ranks
   __shared__ double red[8];
   int e = (blockIdx.x * kThreads + threadIdx.x) >> 4;
   int sub = threadIdx.x & 15;
@@ -863,8 +890,11 @@ __global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, const i
   double s = 0.0, h = 0.0;
   if (e < NE) {
     for (int q = ptr[e] + sub; q < ptr[e + 1]; q += 16) { double v = nu[col[q]]; s += val[q] * (v < 0.0 ? v : 0.0); }
-    for (int q = sptr[e] + sub; q < sptr[e + 1]; q += 16) { long long o = soff[q]; h += nu[ng + o] - w[ng + o]; }
-    if (!isdiag[e]) h *= kSqrt2;
+    if (hsum) { if (sub == 0) h = hsum[e]; }
+    else {
+      for (int q = sptr[e] + sub; q < sptr[e + 1]; q += 16) { long long o = soff[q]; h += nu[ng + o] - w[ng + o]; }
+      if (!isdiag[e]) h *= kSqrt2;
+    }
   }
   s += h;
 #pragma unroll

@@ -357,6 +357,11 @@ class Solver:
         _lib.check(self.lib.nnsdp_solver_iterate(self.h, int(iters), C.byref(ms) if time_eig else None))
         return ms.value
 
+    def set_comm(self, nranks: int, rank: int, unique_id: bytes) -> None:
+        """clique-sharded mode: call on every rank with rank 0's id (comm_unique_id) before iterating."""
+        assert len(unique_id) == 128
+        _lib.check(self.lib.nnsdp_solver_set_comm(self.h, int(nranks), int(rank), unique_id))
+
     def iterate_async(self, iters: int) -> None:
         _lib.check(self.lib.nnsdp_solver_iterate_async(self.h, int(iters)))
 
@@ -388,6 +393,13 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+
+def comm_unique_id() -> bytes:
+    """RCCL unique id (128 bytes) for the clique-sharded mode; generate on rank 0, broadcast to all ranks."""
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().nnsdp_comm_unique_id(buf))
+    return buf.raw
 
 
 class SolverBatch:

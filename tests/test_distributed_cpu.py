@@ -72,3 +72,91 @@ def test_two_rank_gloo_matches_serial():
     serial = [_solve_unit(u) for u in range(len(UNITS))]
     assert np.allclose(res, serial, rtol=0, atol=0)           # same arithmetic, same answers
     assert abs(rate - (3 * 150) / 2.0) < 1e-9                 # sum of units / max of times
+
+
+# ----------------------------------------------------------------------------- clique-sharded mode (one SDP over ranks)
+def _shard_ranges(nk, world):
+    """contiguous clique ranges balanced by n_k^3: the partition nnsdp_solver::set_comm uses."""
+    cost = np.array(nk, dtype=float) ** 3
+    tot, acc, r = cost.sum(), 0.0, 1
+    start = [0] + [len(nk)] * world
+    for k in range(len(nk)):
+        if r >= world:
+            break
+        acc += cost[k]
+        if acc >= tot * r / world:
+            start[r] = k + 1
+            r += 1
+    return start
+
+
+def _sharded_worker(rank, world, port, out):
+    """the HIP library's clique-sharded iteration restated on the oracle state: own cliques are projected
+    locally, the consensus sum is all-reduced (gloo here, RCCL on the GPUs), the rest is replicated."""
+    import scipy.linalg as sla
+    from oracle import admm as oadmm, operator as oop
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q = helpers.oracle_query(helpers.load_problem("W10-D10", 0))
+    P = oadmm.ScaledProblem(oop.build_operator(q, "single", normalize=True))
+    S = oadmm.AdmmState(P, 0.1, 1.6)
+    st = _shard_ranges(S.nk, world)
+    own = range(st[rank], st[rank + 1])
+    for _ in range(40):
+        nu = S.nu
+        w = np.zeros_like(nu)
+        w[:S.ng] = np.maximum(nu[:S.ng], 0.0)
+        h = np.zeros(P.pat.NE)
+        for k in own:
+            n = S.nk[k]
+            V = nu[S.offs[k]:S.offs[k + 1]].reshape(n, n)
+            Wk = oadmm.project_psd(V)
+            w[S.offs[k]:S.offs[k + 1]] = Wk.ravel()
+            R = 2.0 * Wk - 0.5 * (V + V.T)
+            np.add.at(h, S.trilpos[k], R[S.tril[k]] * S.trilw[k])
+        ht = torch.from_numpy(h)
+        dist.all_reduce(ht, op=dist.ReduceOp.SUM)             # the one exchange step per iteration
+        g = S.Dinv * (P.z0 / S.sigma + ht.numpy())
+        p = 2.0 * w[:S.ng] - nu[:S.ng] - P.c
+        ww = sla.cho_solve(S.Mfac, S.At @ g - p)
+        x = g - S.Dinv * (S.A @ ww)
+        new = nu.copy()
+        new[:S.ng] = nu[:S.ng] + S.alpha * (p + ww + P.c - w[:S.ng])
+        for k in own:
+            sl = slice(S.offs[k], S.offs[k + 1])
+            new[sl] = nu[sl] + S.alpha * (x[S.G[k]] * S.Wm[k] - w[sl])
+        S.nu = new
+    # assemble the distributed state: multiplier block is replicated, clique blocks live on their owners
+    full = torch.zeros(S.N, dtype=torch.float64)
+    for k in own:
+        full[S.offs[k]:S.offs[k + 1]] = torch.from_numpy(S.nu[S.offs[k]:S.offs[k + 1]])
+    dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    full[:S.ng] = torch.from_numpy(S.nu[:S.ng])
+    if rank == 0:
+        out.put((full.numpy(), st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_clique_sharded_iteration_matches_serial_gloo():
+    from oracle import admm as oadmm, operator as oop
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    nu_sharded, st = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert st[0] == 0 and 0 < st[1] < st[2] == 9              # 9 cliques of W10-D10 split over 2 ranks
+    q = helpers.oracle_query(helpers.load_problem("W10-D10", 0))
+    S = oadmm.AdmmState(oadmm.ScaledProblem(oop.build_operator(q, "single", normalize=True)), 0.1, 1.6)
+    for _ in range(40):
+        S.step()
+    assert np.abs(nu_sharded - S.nu).max() <= 1e-11 * max(1.0, np.abs(S.nu).max())

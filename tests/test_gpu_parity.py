@@ -365,6 +365,32 @@ def test_solver_batch_matches_single_solves():
         assert np.allclose(r, r1, rtol=1e-9, atol=1e-14)
 
 
+def test_clique_sharded_mode_single_rank_rccl():
+    """the clique-sharded code path (own-clique projection, RCCL all-reduce of the consensus sum, replicated
+    operator kernels) with a one-rank communicator must reproduce the unsharded iteration.  Multi-rank logic is
+    covered on CPU by tests/test_distributed_cpu.py (gloo, world size 2)."""
+    d = helpers.load_problem("W10-D10", 0)
+    q = helpers.product_query(d)
+    opts = na.AdmmSdpOptions(max_iters=10 ** 8, proj_tol=1e-12)
+    a = na.Solver(q, opts)
+    a.iterate(250)
+    ra = a.residuals()
+    a.close()
+    b = na.Solver(q, opts)
+    b.set_comm(1, 0, na.comm_unique_id())
+    b.iterate(250)
+    rb = b.residuals()
+    sb = b.finish()
+    b.close()
+    assert np.allclose(ra, rb, rtol=1e-8, atol=1e-13), (ra, rb)
+    assert np.isfinite(sb.objective_value)
+    c = na.Solver(q, opts)
+    c.iterate(5)
+    with pytest.raises(na._lib.NnsdpError):
+        c.set_comm(1, 0, na.comm_unique_id())                # only before the first iteration
+    c.close()
+
+
 def test_solver_argument_errors():
     d = helpers.load_problem("W10-D5", 0)
     q = helpers.product_query(d)
