@@ -35,7 +35,8 @@ enum { NNSDP_QUERY_SAFETY = 0, NNSDP_QUERY_REACH = 1 };
 enum { NNSDP_OUT_SAFETY_S = 0, NNSDP_OUT_HPLANE = 1, NNSDP_OUT_CIRCLE = 2, NNSDP_OUT_ELLIPSOID = 3 };
 /* decomp_mode: DeepSdpOptions (one dense cone, src/Methods/deep_sdp.jl:2-7) or
  * ChordalSdpOptions.decomp_mode = SingleDecomp / DoubleDecomp (src/Methods/chordal_sdp.jl:4-16) */
-enum { NNSDP_DECOMP_DENSE = 0, NNSDP_DECOMP_SINGLE = 1, NNSDP_DECOMP_DOUBLE = 2 };
+enum { NNSDP_DECOMP_DENSE = 0, NNSDP_DECOMP_SINGLE = 1, NNSDP_DECOMP_DOUBLE = 2,
+       NNSDP_DECOMP_PATH = 3 /* extension: cliques {x_k, x_k+1, affine}, exact when the output QC has S12 = 0 */ };
 /* termination status; strings as consumed by experiments/acas.jl:77 via nnsdp_status_string() */
 enum { NNSDP_STATUS_OPTIMAL = 0, NNSDP_STATUS_ITERATION_LIMIT = 1, NNSDP_STATUS_TIME_LIMIT = 2,
        NNSDP_STATUS_SLOW_PROGRESS = 3, NNSDP_STATUS_NUMERICAL_ERROR = 4 };

@@ -246,7 +246,7 @@ struct nnsdp_solver {
     if (!(opt.alpha > 0.0 && opt.alpha < 2.0)) throw std::invalid_argument("alpha must be in (0,2)");
     if (!(opt.sigma > 0.0)) throw std::invalid_argument("sigma must be > 0");
     if (opt.check_every <= 0) opt.check_every = 50;
-    if (opt.decomp_mode < NNSDP_DECOMP_DENSE || opt.decomp_mode > NNSDP_DECOMP_DOUBLE)
+    if (opt.decomp_mode < NNSDP_DECOMP_DENSE || opt.decomp_mode > NNSDP_DECOMP_PATH)
       throw std::invalid_argument("unrecognized decomp_mode");
     P.load(prob);
     require_gpu();
@@ -266,7 +266,14 @@ struct nnsdp_solver {
       if (std::find(cl.begin(), cl.end(), r) == cl.end()) cl.push_back(r);
     }
     Pattern pt = build_pattern(C.nred, cl);
-    Operator op = OperatorBuilder(P, C, pt).build();
+    Operator op;
+    try {
+      op = OperatorBuilder(P, C, pt).build();
+    } catch (const std::runtime_error& e) {
+      if (opt.decomp_mode == NNSDP_DECOMP_PATH)
+        throw std::invalid_argument(std::string("PATH decomposition needs an output QC without x_1 -- x_K coupling (S12 = 0): ") + e.what());
+      throw;
+    }
     S = scale_operator(op, opt.normalize != 0);
     pat = std::move(op.pat);
     D.upload(S, pat);
@@ -1011,7 +1018,7 @@ int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t mo
   API_BEGIN
   if (!xdims || K < 2) throw std::invalid_argument("bad xdims / K");
   if (beta < 0) throw std::invalid_argument("beta must be >= 0");
-  if (mode < NNSDP_DECOMP_DENSE || mode > NNSDP_DECOMP_DOUBLE) throw std::invalid_argument("unrecognized decomp_mode");
+  if (mode < NNSDP_DECOMP_DENSE || mode > NNSDP_DECOMP_PATH) throw std::invalid_argument("unrecognized decomp_mode");
   auto cl = clique_index_sets(K, xdims, beta, mode);
   int tot = 0;
   for (auto& c : cl) tot += (int)c.size();

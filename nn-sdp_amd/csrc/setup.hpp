@@ -122,6 +122,20 @@ inline std::vector<std::vector<int>> clique_index_sets(int K, const int* xdims, 
     out.push_back(all);
     return out;
   }
+  if (mode == NNSDP_DECOMP_PATH) {
+    // extension (not in the reference): without an x_1 -- x_K coupling (S12 = 0: every reach query and hyperplane
+    // safety sets) the sparsity graph of Z is the path x_1 - x_2 - ... - x_K plus the affine index, which is
+    // chordal as it stands: cliques {x_k, x_{k+1} (+ beta spill), a} of size ~2W+1 instead of 3W+1.  The
+    // generator builder rejects the mode when an entry falls outside these blocks.
+    for (int k = 1; k <= K - 1; ++k) {
+      std::vector<int> Ck;
+      int hi = std::min(S[k + 1] + beta, S[K]);
+      for (int i = S[k - 1]; i < hi; ++i) Ck.push_back(i);
+      Ck.push_back(S[K]);
+      out.push_back(Ck);
+    }
+    return out;
+  }
   int p = 1;
   for (int i = 1; i <= K; ++i)
     if (S[i + 1] + beta >= S[K - 1]) { p = i; break; }

@@ -3,7 +3,7 @@ reference's Methods/Qc API over the C ABI in include/nnsdp.h)."""
 from .methods import (  # noqa: F401
     FeedFwdNet, QcInputBox, QcSafety, QcReachHplane, QcReachCircle, QcReachEllipsoid,
     QcActivBounded, QcActivSector, SafetyQuery, ReachQuery, AdmmSdpOptions, QuerySolution,
-    SingleDecomp, DoubleDecomp, DenseCone, Solver, SolverBatch,
+    SingleDecomp, DoubleDecomp, PathDecomp, DenseCone, Solver, SolverBatch,
     runQuery, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched, comm_unique_id,
 )
 from .frontend import (  # noqa: F401

@@ -38,6 +38,11 @@ class DoubleDecomp:
     code = 2
 
 
+class PathDecomp:
+    """extension: cliques {x_k, x_{k+1}, affine}; exact when the output QC has no x_1 -- x_K coupling."""
+    code = 3
+
+
 class DenseCone:
     """DeepSdpOptions' single dense cone (src/Methods/deep_sdp.jl:57)."""
     code = 0

@@ -391,6 +391,12 @@ def clique_index_sets(net: FeedFwdNet, beta: int, mode: str = "single") -> List[
     src/Methods/deep_sdp.jl:57)."""
     if mode == "dense":
         return [list(range(net.Zdim))]
+    if mode == "path":
+        # extension of this build (not in the reference): cliques {x_k, x_{k+1} (+beta spill), a}; exact when the
+        # output QC has no x_1 -- x_K coupling (S12 = 0), see nn-sdp_amd/csrc/setup.hpp
+        S = np.concatenate([[0], np.cumsum(net.xdims)]).astype(int)
+        K = net.K
+        return [list(range(S[k - 1], min(S[k + 1] + beta, S[K]))) + [int(S[K])] for k in range(1, K)]
     out = []
     for Ck, _, Dks in make_cliques(net, beta):
         if mode == "single" or len(Dks) == 1:

@@ -185,13 +185,14 @@ def test_decomposition_modes_agree():
     d = helpers.load_problem("W10-D5", 0)
     q = helpers.product_query(d)
     rho = {}
-    for mode in (na.SingleDecomp(), na.DoubleDecomp(), na.DenseCone()):
+    for mode in (na.SingleDecomp(), na.DoubleDecomp(), na.DenseCone(), na.PathDecomp()):
         s = na.runQuery(q, na.AdmmSdpOptions(max_iters=4000, decomp_mode=mode))
         assert s.termination_status == "OPTIMAL"
         rho[type(mode).__name__] = s.objective_value
     # reference: the three methods agree to ~1e-4 relative on every OPTIMAL row
     assert abs(rho["SingleDecomp"] - rho["DenseCone"]) <= 2e-4 * rho["DenseCone"]
     assert abs(rho["DoubleDecomp"] - rho["DenseCone"]) <= 1e-3 * rho["DenseCone"]
+    assert abs(rho["PathDecomp"] - rho["DenseCone"]) <= 2e-4 * rho["DenseCone"]     # exact decomposition (extension)
 
 
 @pytest.mark.parametrize("out", ["hplane", "circle", "safety"])
@@ -337,6 +338,15 @@ def test_acas_shaped_safety_query_tracks_oracle():
     with pytest.raises(na._lib.NnsdpError) as ei:
         na.runQuery(acas, na.AdmmSdpOptions(max_iters=10))
     assert "128" in str(ei.value) and ei.value.code < 0
+    # the path decomposition (extension, exact for hyperplane safety sets: S12 = 0) keeps width-50 blocks at 2W+1 = 101
+    sp = na.runQuery(acas, na.AdmmSdpOptions(max_iters=60, decomp_mode=na.PathDecomp()))
+    assert sp.summary["max_clique"] <= 103 and np.isfinite(sp.objective_value)
+    # ... and is refused when the safety set couples x_1 with the output
+    Sc = S.copy(); Sc[0, 5] = Sc[5, 0] = 1.0
+    acas2 = na.SafetyQuery(ffnet=acas.ffnet, qc_input=acas.qc_input, qc_safety=na.QcSafety(S=Sc), qc_activs=acas.qc_activs)
+    with pytest.raises(na._lib.NnsdpError) as ei2:
+        na.runQuery(acas2, na.AdmmSdpOptions(max_iters=10, decomp_mode=na.PathDecomp()))
+    assert "S12" in str(ei2.value)
     iters = 400
     s = na.runQuery(q, na.AdmmSdpOptions(max_iters=iters, proj_tol=1e-12, polish=False))
     r = oadmm.admm_solve(oop.build_operator(qo, "single", normalize=True), oadmm.AdmmOptions(max_iters=iters))

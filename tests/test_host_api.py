@@ -49,7 +49,7 @@ def test_struct_layout_matches_header_field_count():
 def test_make_cliques_matches_oracle(xdims, beta):
     from oracle.nnet_io import random_net
     net = random_net(xdims, seed=1)
-    for mode, omode in ((na.SingleDecomp, "single"), (na.DoubleDecomp, "double"), (na.DenseCone, "dense")):
+    for mode, omode in ((na.SingleDecomp, "single"), (na.DoubleDecomp, "double"), (na.DenseCone, "dense"), (na.PathDecomp, "path")):
         assert na.makeCliques(xdims, beta, mode) == qc.clique_index_sets(net, beta, omode)
 
 
@@ -76,6 +76,7 @@ def test_invalid_arguments_return_negative_codes():
     xd = np.asarray([2, 3, 3, 2], dtype=np.int32)
     assert lib.nnsdp_make_cliques(3, xd.ctypes.data_as(_lib.c_int32_p), -1, 1, C.byref(n), C.byref(t), None, None) < 0  # beta < 0
     assert lib.nnsdp_make_cliques(3, xd.ctypes.data_as(_lib.c_int32_p), 0, 9, C.byref(n), C.byref(t), None, None) < 0   # mode
+    assert [len(c) for c in na.makeCliques([5] + [50] * 6 + [5], 0, na.PathDecomp)] == [56] + [101] * 5   # 2W+1, not 3W+1
     with pytest.raises(_lib.NnsdpError):
         na.project_psd_batched([np.zeros((200, 200))])          # n > 128 (checked before any device use)
     with pytest.raises(ValueError):
