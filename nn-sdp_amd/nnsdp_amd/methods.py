@@ -410,7 +410,9 @@ def comm_unique_id() -> bytes:
 class SolverBatch:
     """Independent SDPs solved side by side on one GPU (one HIP stream each): the beta sweep of
     experiments/scale.jl:28 or the hyperplane directions of NnSdp.findReach2Dpoly (src/NnSdp.jl:73-95).
-    A single W40-D20 SDP occupies 19 of the 256 CUs; a batch fills the chip with the same kernels."""
+    A single W40-D20 SDP occupies 19 of the 256 CUs; a batch fills the chip with the same kernels.  Set
+    GPU_MAX_HW_QUEUES (e.g. 16) in the environment before HIP initialises: with the default 4 hardware queues
+    at most 4 streams make progress at a time."""
 
     def __init__(self, queries, opts: AdmmSdpOptions):
         self.solvers = [Solver(q, opts) for q in queries]
