@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   //  * 2x2 blocks of the lower block triangle; block rows ia and half-1-ia are paired into rows of equal
   //    length half+1 and the rectangle ceil(half/2) x (half+1) is dealt out thread by thread
   //  * eigenvector units (pair slot, chunk of 32 rows) dealt out to 32-lane groups of all waves but the last
-  constexpr int MAXB = (NT == 1024) ? 3 : 9;
+  constexpr int MAXB = (NT == 1024) ? (V_LDS ? 2 : 3) : 9;   // ceil(ceil(half/2) * (half+1) / NT): half <= 48 with V in LDS
   // ceil(half * ceil(nv/32) / VG) for the sizes each variant is launched with (n <= 96 when V is in LDS)
   constexpr int MAXU = (NT == 1024) ? (V_LDS ? 5 : 9) : 7;   // V in HBM: blocks up to n = 128
   constexpr int VG = (NT - 64) / 32;
