@@ -215,7 +215,8 @@ struct nnsdp_solver {
   int graph_iters = 0;
   std::vector<hipEvent_t> ev;
   std::unique_ptr<RocHandle> roc;
-  long long iters_done = 0, next_adapt = 0, next_trace = 0, next_cert = 500;
+  long long iters_done = 0, next_adapt = 0, next_trace = 0, next_cert = 500, best_iter = 0;
+  double best_res = 1e300;
   int trace_polish = 0;
   int since_cold = 0;
   double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
@@ -601,6 +602,12 @@ struct nnsdp_solver {
         }
       }
       if (opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
+      // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
+      {
+        double worst = std::max(last_pres, last_dres);
+        if (worst < 0.9 * best_res) { best_res = worst; best_iter = iters_done; }
+        else if (iters_done - best_iter >= 50000) { status = NNSDP_STATUS_SLOW_PROGRESS; break; }
+      }
       // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
       if (opt.adapt_every > 0 && iters_done >= next_adapt) {
         next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, iters_done * 3 / 2);
