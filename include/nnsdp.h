@@ -133,6 +133,9 @@ int nnsdp_solver_create(const nnsdp_problem* p, const nnsdp_options* o, nnsdp_so
 /* run `iters` ADMM iterations (no convergence test); eig_ms (may be NULL) receives the HIP-event
  * time of the projection kernel summed over these iterations. */
 int nnsdp_solver_iterate(nnsdp_solver* s, int32_t iters, double* eig_ms);
+/* advance exactly `iters` iterations with the solve loop's convergence checks and sigma / projection-tolerance
+ * adaptation, but without stopping (brings a handle to the solver's steady state before timing) */
+int nnsdp_solver_advance(nnsdp_solver* s, int32_t iters);
 /* enqueue `iters` iterations on the solver's own HIP stream without waiting: several handles (independent
  * SDPs: the beta sweep of experiments/scale.jl:28, the hyperplanes of NnSdp.findReach2Dpoly) then run
  * concurrently on one GPU; nnsdp_solver_sync waits for one handle. */

@@ -554,14 +554,18 @@ struct nnsdp_solver {
     sigma = ns;
   }
 
-  int run_loop() {
+  // cap < 0: run to opt.max_iters with the stopping tests; cap >= 0: advance exactly `cap` more iterations with the
+  // same checks and sigma / tolerance adaptation but without stopping (bench burn-in)
+  int run_loop(long long cap = -1) {
     double t0 = now_s();
     int status = NNSDP_STATUS_ITERATION_LIMIT;
+    const bool advance_only = cap >= 0;
+    const long long limit = advance_only ? iters_done + cap : (long long)opt.max_iters;
     int ce = opt.check_every;
     if (next_adapt == 0) next_adapt = opt.adapt_every;
     if (const char* e = std::getenv("NNSDP_TRACE_POLISH")) trace_polish = std::atoi(e);
-    while (iters_done < opt.max_iters) {
-      int n = (int)std::min<long long>(ce - 1, opt.max_iters - iters_done - 1);
+    while (iters_done < limit) {
+      int n = (int)std::min<long long>(ce - 1, limit - iters_done - 1);
       iterate(n, nullptr);
       check_iteration();
       if (opt.verbose)
@@ -581,10 +585,10 @@ struct nnsdp_solver {
         std::fprintf(stderr, "[nnsdp] it %6lld t %.2f polished rho %.8g (ok %d shift %.2e) admm %.8g dobj %.8g pres %.1e dres %.1e polish_ms %.0f\n", iters_done,
                      now_s() - t0, o / (S.zscale * S.cscale), (int)ok, polish_shift, last_pobj, last_dobj, last_pres, last_dres, 1e3 * (now_s() - tp));
       }
-      if (last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
+      if (!advance_only && last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
       // optional early stop on the CERTIFIED objective: the polished point is exactly feasible, so once it
       // is within cert_tol of the ADMM estimate of the optimum the certificate is as good as it gets
-      if (opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= 1e-3) {
+      if (!advance_only && opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= 1e-3) {
         next_cert = std::max<long long>(iters_done + 250, iters_done * 5 / 4);
         hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
         HIPCHK(hipStreamSynchronize(st));
@@ -601,12 +605,12 @@ struct nnsdp_solver {
           }
         }
       }
-      if (opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
+      if (!advance_only && opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
       // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
       {
         double worst = std::max(last_pres, last_dres);
         if (worst < 0.9 * best_res) { best_res = worst; best_iter = iters_done; }
-        else if (iters_done - best_iter >= 50000) { status = NNSDP_STATUS_SLOW_PROGRESS; break; }
+        else if (!advance_only && iters_done - best_iter >= 50000) { status = NNSDP_STATUS_SLOW_PROGRESS; break; }
       }
       // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
       if (opt.adapt_every > 0 && iters_done >= next_adapt) {
@@ -923,6 +927,14 @@ int nnsdp_solver_iterate(nnsdp_solver* s, int32_t iters, double* eig_ms) {
   double t0 = now_s();
   s->iterate(iters, eig_ms);
   s->t_solve += now_s() - t0;
+  API_END
+}
+
+int nnsdp_solver_advance(nnsdp_solver* s, int32_t iters) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  if (iters < 0) throw std::invalid_argument("iters must be >= 0");
+  if (iters > 0) (void)s->run_loop(iters);
   API_END
 }
 

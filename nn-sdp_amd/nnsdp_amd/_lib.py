@@ -64,6 +64,7 @@ SYMBOLS = [
     ("nnsdp_solve", C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.POINTER(Result)]),
     ("nnsdp_solver_create", C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.POINTER(C.c_void_p)]),
     ("nnsdp_solver_iterate", C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    ("nnsdp_solver_advance", C.c_int, [C.c_void_p, C.c_int32]),
     ("nnsdp_solver_iterate_async", C.c_int, [C.c_void_p, C.c_int32]),
     ("nnsdp_solver_sync", C.c_int, [C.c_void_p]),
     ("nnsdp_solver_residuals", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),

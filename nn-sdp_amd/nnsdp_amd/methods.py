@@ -362,6 +362,10 @@ class Solver:
         _lib.check(self.lib.nnsdp_solver_iterate(self.h, int(iters), C.byref(ms) if time_eig else None))
         return ms.value
 
+    def advance(self, iters: int) -> None:
+        """`iters` iterations with the solve loop's checks and sigma / tolerance adaptation, without stopping."""
+        _lib.check(self.lib.nnsdp_solver_advance(self.h, int(iters)))
+
     def set_comm(self, nranks: int, rank: int, unique_id: bytes) -> None:
         """clique-sharded mode: call on every rank with rank 0's id (comm_unique_id) before iterating."""
         assert len(unique_id) == 128
@@ -416,6 +420,10 @@ class SolverBatch:
 
     def __init__(self, queries, opts: AdmmSdpOptions):
         self.solvers = [Solver(q, opts) for q in queries]
+
+    def advance(self, iters: int) -> None:
+        for s in self.solvers:
+            s.advance(iters)
 
     def iterate(self, iters: int, chunk: int = 64) -> None:
         done = 0
