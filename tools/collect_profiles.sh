@@ -8,7 +8,8 @@ OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 200 --warmup 50 --no-cpu-baseline --cert-seconds 0"
+BURN=2000; WARM=50; STEPS=200
+ARGS="--steps $STEPS --warmup $WARM --burn-in $BURN --batch 0 --no-cpu-baseline --cert-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_$C.err
@@ -16,9 +17,10 @@ done
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_LDS -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_LDS.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_SQ.err || true
 cd $R
-python3 - "$OUT" "$TAG" <<'PY'
+python3 - "$OUT" "$TAG" $BURN $WARM $STEPS <<'PY'
 import csv, collections, glob, json, sys, shutil
 out, tag = sys.argv[1], sys.argv[2]
+burn, warm, steps = (int(x) for x in sys.argv[3:6])
 res = collections.defaultdict(dict)
 for path in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -33,6 +35,16 @@ for path in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
 json.dump(res, open(f"{out}/{tag}_pmc_counters_W40-D20.json", "w"), indent=1)
 for p in glob.glob(out + "/stats/*/*kernel_stats.csv"):
     shutil.copy(p, f"{out}/{tag}_bench_W40-D20_kernel_stats.csv")
+# the projection kernel's launches in dispatch order: burn-in, warmup, then the timed window bench.py brackets with HIP events
+for p in glob.glob(out + "/stats/*/*kernel_trace.csv"):
+    with open(p) as f:
+        d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(f) if "k_proj_jacobi" in r["Kernel_Name"])
+    dur = [(e - s) / 1e3 for s, e in d]
+    win = dur[burn + warm: burn + warm + steps]
+    json.dump({"kernel": "k_proj_jacobi", "launches": len(dur), "avg_us_all_launches": sum(dur) / len(dur),
+               "timed_window": {"first_launch": burn + warm, "launches": len(win), "avg_us": sum(win) / max(len(win), 1)},
+               "burn_in_avg_us": sum(dur[:burn]) / max(burn, 1)},
+              open(f"{out}/{tag}_kernel_trace_window.json", "w"), indent=1)
 k = [v for kk, v in res.items() if "k_proj_jacobi" in kk]
 if k:
     k = k[0]
