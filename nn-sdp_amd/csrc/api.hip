@@ -77,10 +77,18 @@ static void require_gpu() {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// NNSDP_BLOCK=0/1 selects the element-wise / block (MFMA) Jacobi kernel (diagnostic override)
-static bool block_mode_requested() {
-  const char* e = std::getenv("NNSDP_BLOCK");
-  return e ? std::atoi(e) != 0 : false;
+// projection kernel variant for a launch whose largest block is nmax.  Default: ping-pong odd-even sweeps for
+// 41..96, register-resident systolic sweeps for 97..128, LDS round robin for small blocks.
+// Diagnostic overrides: NNSDP_PROJ_ALG=0/1/2/3, NNSDP_BLOCK=1.
+static int proj_algorithm(int nmax) {
+  int alg = nnsdp::proj_pp_ok(nmax) ? nnsdp::kProjPingPong : (nnsdp::proj_sys_ok(nmax) ? nnsdp::kProjSystolic : nnsdp::kProjRoundRobin);
+  if (const char* e = std::getenv("NNSDP_PROJ_ALG")) alg = std::atoi(e);
+  if (const char* e = std::getenv("NNSDP_BLOCK")) { if (std::atoi(e) != 0) alg = nnsdp::kProjBlock; }
+  if (alg == nnsdp::kProjSystolic && !nnsdp::proj_sys_ok(nmax)) alg = nnsdp::kProjRoundRobin;
+  if (alg == nnsdp::kProjBlock && !nnsdp::proj_block_ok(nmax)) alg = nnsdp::kProjRoundRobin;
+  if (alg == nnsdp::kProjPingPong && !nnsdp::proj_pp_ok(nmax)) alg = nnsdp::kProjRoundRobin;
+  if (alg < 0 || alg > 3) alg = nnsdp::kProjRoundRobin;
+  return alg;
 }
 
 // device-resident operator (CSR + CSC + pattern)
@@ -198,7 +206,8 @@ struct nnsdp_solver {
   std::vector<long long> coff;
   long long nmat = 0;
   int ncl = 0, nmax = 0;
-  bool v_lds = true, use_block = false;
+  bool v_lds = true;
+  int proj_alg = 0;
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
@@ -293,9 +302,9 @@ struct nnsdp_solver {
     if (nmax > 128 && opt.decomp_mode != NNSDP_DECOMP_DENSE)
       throw std::invalid_argument("clique larger than 128 is not supported by the LDS-resident projection kernel");
     if (nmax > 128) throw std::invalid_argument("dense mode supports Zdim <= 128 only (use a chordal decomp_mode)");
-    v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
-    use_block = block_mode_requested() && proj_block_ok(nmax);
-    lds_bytes = proj_lds_bytes(nmax, v_lds, use_block);
+    proj_alg = proj_algorithm(nmax);
+    v_lds = proj_lds_bytes(nmax, true, proj_alg) <= 160 * 1024;
+    lds_bytes = proj_lds_bytes(nmax, v_lds, proj_alg);
     // gather sources: entry e <- (clique k, lower element (i,j))
     std::vector<int> sptr(S.NE + 1, 0);
     for (int k = 0; k < ncl; ++k) {
@@ -421,7 +430,7 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, use_block);
+    if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
   }
 
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
@@ -1075,9 +1084,9 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   dcn.upload(cn); dco.upload(coff); deo.upload(eoff);
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dE.alloc(etot);
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
-  bool v_lds = proj_lds_bytes(nmax, true) <= 160 * 1024;
-  bool use_block = block_mode_requested() && proj_block_ok(nmax);
-  size_t lds = proj_lds_bytes(nmax, v_lds, use_block);
+  const int alg = proj_algorithm(nmax);
+  bool v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
+  size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
@@ -1085,7 +1094,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
-  launch_proj(a, batch, nmax, v_lds, lds, nullptr, use_block);
+  launch_proj(a, batch, nmax, v_lds, lds, nullptr, alg);
   HIPCHK(hipEventRecord(e1, nullptr));
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());

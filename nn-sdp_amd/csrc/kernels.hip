@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace nnsdp {
 
@@ -129,28 +130,62 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// neighbour-lane moves of an fp64 value on the DPP path (no LDS): lane i receives lane i+1 / lane i-1 across the
+// whole 64-lane wave (wave_shl / wave_shr; verified on gfx950), 0 beyond the wave's ends
+__device__ __forceinline__ double lane_next(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_prev(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// value of lane l (wave-uniform l) in every lane
+__device__ __forceinline__ double lane_bcast(double x, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+// LDS scratch of the register-resident (systolic) sweeps, in doubles: rotation inputs prm[2][65][4] and the
+// boundary rows halo[NW][2][64][2] exchanged between neighbouring waves
+static constexpr int kSysPrm = 2 * 65 * 4;
+__host__ __device__ constexpr int sys_scratch_doubles(int nw) { return kSysPrm + nw * 256; }
+static constexpr int kSysHead = 16 + 66;   // red[16], sel[npg + 2 <= 130 ints] in front of A (fixed offsets)
+
 // BLOCK = true: block Jacobi.  Indices are grouped in blocks of 8; a round pairs the blocks (round robin),
 // one wave diagonalises each 16x16 diagonal sub-problem in place (one cyclic sweep, rotations accumulated
 // in a 16x16 J), then A <- J'AJ and V <- VJ are applied as 16x16x16 products on v_mfma_f64_16x16x4_f64.
 // 3 workgroup barriers per block round (nb-1 block rounds per sweep) instead of 2 per element round.
-template <bool V_LDS, int NT, bool BLOCK = false>
+// ALG = 2: register-resident systolic sweeps (below).  SPW = pair slots (2 matrix rows each) per wave, RPW = eigenvector
+// rows per wave; NT/64 * SPW >= ceil(n/2) and NT/64 * RPW >= n + 1 for every block of the launch.
+template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
 __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
+  constexpr bool BLOCK = ALG == 1;
+  constexpr bool SYS = ALG == 2;
+  constexpr bool PP = ALG == 3;
+  static_assert(!PP || (V_LDS && NT == 1024), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
   const int k = blockIdx.x;
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // Jacobi dimension (even)
   const int npg = (n + 15) & ~15;  // storage / MFMA dimension (multiple of 16; zero rows, identity in V)
   const int half = np >> 1;
-  const int lda = npg + 1;       // odd stride (in doubles): column walks hit distinct banks
+  constexpr bool PPL = ALG == 3;   // ping-pong sweeps keep a one-cell border around the matrix: 2 more rows / columns of storage
+  const int lda = PPL ? npg + 3 : npg + 1;   // odd stride (in doubles): column walks hit distinct banks
+  const int nrow = PPL ? npg + 2 : npg;      // rows of LDS storage per matrix
   const int tid = threadIdx.x;
-  double* A = lds;
+  // systolic variant: reduction scratch and the selection list sit in FRONT of A at fixed offsets, because the sweeps
+  // reuse the (then dead) A / V storage as exchange scratch whatever this block's own size is
+  double* A = SYS ? lds + kSysHead : lds;
   // 2 buffers x half pair descriptors {c, s, (p, q), pad} = 4 doubles each, 16-byte aligned
-  double* desc = A + (((size_t)npg * lda + 1) & ~(size_t)1);
-  double* red = desc + (BLOCK ? 0 : 4 * npg);   // block mode needs no pair descriptors                  // 16 doubles of reduction scratch
+  double* desc = A + (((size_t)nrow * lda + 1) & ~(size_t)1);
+  double* red = SYS ? lds : desc + (BLOCK ? 0 : 4 * npg);   // 16 doubles of reduction scratch (block mode: no pair descriptors)
   int* sel = reinterpret_cast<int*>(red + 16);  // npg + 2 ints: eigen-indices on the chosen side, counters
   double* V;
   int ldv;
-  if (V_LDS) { V = red + 16 + (npg >> 1) + 2; ldv = npg + 1; }
+  if (V_LDS) { V = SYS ? desc : red + 16 + (npg >> 1) + 2; ldv = lda; }
   else { V = a.Vg + a.coff[k]; ldv = n; }
   const double* nuk = a.nu + a.coff[k];
   // block mode scratch: per block pair a 16x16 J (row-major) and 16 doubles of rotation parameters
@@ -192,7 +227,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     // Jacobi sweeps read the lower triangle only).  Operand maps (verified on gfx950): lane l holds
     // A[l&15][l>>4], B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
     constexpr int NW = NT / 64;
-    constexpr int MAXT = 3;                    // ceil(36 tiles / 16 waves), ceil(9 / 4)
+    constexpr int MAXT = (NT == 512) ? 5 : 3;  // ceil(36 tiles / 16 waves), ceil(36 / 8), ceil(9 / 4)
     const int nt = npg >> 4, ks = npg >> 2;
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lc = lane >> 4;
@@ -377,6 +412,389 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #define STAMP(i, tprev)
 #endif
   int sweeps = 0;
+  int pofs = 0;   // systolic sweeps: eigen-index j of the result sits at position j + pofs (the padded index travels)
+  if constexpr (PP) {
+    // ---- ping-pong Jacobi: odd-even ordering on matrix POSITIONS (a rotation is followed by a swap of the two
+    // positions, so pairs are always neighbours and no index tables exist).  Round type 0 pairs (2K, 2K+1), type 1
+    // pairs (2K-1, 2K) with virtual positions -1 and np at the ends; np rounds make every pair meet once and reverse
+    // the order.  The lower triangle lives in LDS twice, shifted by one cell so that the virtual positions are a
+    // border of zeros and every 2x2 block of either round type is read and written unconditionally.  A round reads
+    // A_in and writes A_out (the eigenvector copy is not needed during the sweeps, its storage is the second buffer),
+    // so the LAST wave can compute round t+1's rotations from A_in - analytically for the two diagonal entries, from
+    // one 2x2 coupling block for the off-diagonal one - WHILE waves 0..14 apply round t.  One workgroup barrier per
+    // round.  Eigenvectors live in the registers of waves 0..14 (lane = column pair, neighbour columns over DPP).
+    constexpr int UW = NT / 64 - 1;            // updater waves
+    constexpr int VRW = 7;                     // eigenvector rows per updater wave: 15 x 7 >= 96
+    constexpr int MAXI = 2;                    // items per updater thread: (m+1)(m+2)/2 <= 1225 <= 2 x 960
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool updater = wv < UW;
+    const int m = half;
+    double* const B0 = V;                      // shifted buffers: B0 holds the matrix at even rounds
+    double* const B1 = A;
+    double* cs = desc;                         // [2][m + 2] x {c, s}
+    const int csld = 2 * (m + 2);
+    // eigenvector rows -> registers (before the second matrix buffer overwrites the LDS copy)
+    double vr[VRW][2];
+#pragma unroll
+    for (int j = 0; j < VRW; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        int r = j * UW + wv, col = 2 * lane + cc;   // rows dealt round robin over the updater waves
+        vr[j][cc] = (updater && r < np && col < np) ? V[r + (size_t)col * ldv] : 0.0;
+      }
+    // static items of both round types: (ka << 8) | kb and the offset of the block's first element
+    int ik[2][MAXI], eb[2][MAXI];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int mt = m + sg, Wd = mt + 1, R = (mt + 1) >> 1;
+#pragma unroll
+      for (int u = 0; u < MAXI; ++u) {
+        int b = tid + u * (UW * 64);
+        int v = -1;
+        if (updater && b < R * Wd) {
+          int row = b / Wd, c = b - row * Wd;
+          int hi = mt - 1 - row;
+          if (c <= row) v = (row << 8) | c;
+          else if (hi != row) v = (hi << 8) | (c - row - 1);
+        }
+        ik[sg][u] = v;
+        eb[sg][u] = (2 * (v >> 8) + 1 - sg) * lda + 2 * (v & 255) + 1 - sg;
+      }
+    }
+    __syncthreads();
+    // shifted copy (lower triangle) with a border of zeros, then the border of the other buffer
+    for (int i = tid >> 6; i < np; i += NT >> 6)
+      for (int j = tid & 63; j <= i; j += 64) B0[(i + 1) * lda + j + 1] = A[i * lda + j];
+    for (int i = tid; i < np + 2; i += NT) { B0[i * lda] = 0.0; B0[(np + 1) * lda + i] = 0.0; }
+    __syncthreads();
+    for (int i = tid; i < np + 2; i += NT) { B1[i * lda] = 0.0; B1[(np + 1) * lda + i] = 0.0; }
+    // parameter wave state: (pp, qq, pq) of pair `lane` of the current round, its rotation (pc, ps)
+    double st_pp = 0.0, st_qq = 0.0, st_pq = 0.0, pc = 1.0, ps = 0.0;
+    for (;;) {
+      double off2 = 0.0;
+      for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
+        for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[i * lda + j]; off2 += v * v; }
+      off2 = 2.0 * block_sum(off2, red);
+      if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
+      if (!updater) {   // rotations of round 0 (type 0) straight from the matrix
+        if (lane < m) {
+          const double* d = B0 + (2 * lane + 1) * lda + 2 * lane + 1;
+          st_pp = d[0]; st_qq = d[lda + 1]; st_pq = d[lda];
+          jacobi_cs(st_pp, st_qq, st_pq, rot_thr, pc, ps);
+          nrot += (ps != 0.0);
+          *reinterpret_cast<double2*>(cs + 2 * lane) = make_double2(pc, ps);
+        } else { st_pp = st_qq = st_pq = 0.0; pc = 1.0; ps = 0.0; }
+      }
+      __syncthreads();
+      auto round = [&](auto sgc, int t) {
+        constexpr int sg = decltype(sgc)::value;   // round type as a constant: the static item tables stay in registers
+        const double* Ain = sg ? B1 : B0;
+        double* Aout = sg ? B0 : B1;
+        const double* csr = cs + sg * csld;
+#ifdef PP_NO_UPDATE
+        if (false) {
+#else
+        if (updater) {
+#endif
+          // A_out <- M_r' A_in M_c on the lower block triangle, M = [s c; c -s] (rotation + swap)
+#ifndef PP_NO_A
+#pragma unroll
+          for (int u = 0; u < MAXI; ++u) {
+            const int it = ik[sg][u];
+            if (it >= 0) {
+              const int ka = it >> 8, kb = it & 255;
+              const double* src = Ain + eb[sg][u];
+              double* dst = Aout + eb[sg][u];
+              const double2 pr = *reinterpret_cast<const double2*>(csr + 2 * ka);
+              const double2 pq = *reinterpret_cast<const double2*>(csr + 2 * kb);
+              const double b00 = src[0], b10 = src[lda], b11 = src[lda + 1];
+              const double b01 = (ka == kb) ? b10 : src[1];
+              const double t00 = pq.y * b00 + pq.x * b01, t01 = pq.x * b00 - pq.y * b01;
+              const double t10 = pq.y * b10 + pq.x * b11, t11 = pq.x * b10 - pq.y * b11;
+              dst[0] = pr.y * t00 + pr.x * t10;
+              dst[lda] = pr.x * t00 - pr.y * t10;
+              dst[lda + 1] = pr.x * t01 - pr.y * t11;
+              if (ka != kb) dst[1] = pr.y * t01 + pr.x * t11;
+            }
+          }
+#endif
+#ifndef PP_NO_V
+          // eigenvector columns (registers)
+          if (sg == 0) {
+            const double2 p = *reinterpret_cast<const double2*>(csr + 2 * lane);
+            const double c = lane < m ? p.x : 1.0, sn = lane < m ? p.y : 0.0;
+#pragma unroll
+            for (int j = 0; j < VRW; ++j) {
+              if (j * UW + wv < np) {
+                double x0 = vr[j][0], x1 = vr[j][1];
+                vr[j][0] = sn * x0 + c * x1;
+                vr[j][1] = c * x0 - sn * x1;
+              }
+            }
+          } else {
+            // position 2J is the second of pair J = (2J-1, 2J); position 2J+1 the first of pair J+1
+            double2 p0 = *reinterpret_cast<const double2*>(csr + 2 * lane);
+            double2 p1 = *reinterpret_cast<const double2*>(csr + 2 * lane + 2);
+            if (lane >= m) { p0 = make_double2(0.0, -1.0); p1 = make_double2(0.0, 1.0); }
+#pragma unroll
+            for (int j = 0; j < VRW; ++j) {
+              if (j * UW + wv < np) {
+                double x0 = vr[j][0], x1 = vr[j][1];
+                double xp = lane_prev(x1), xq = lane_next(x0);
+                vr[j][0] = p0.x * xp - p0.y * x0;
+                vr[j][1] = p1.y * x1 + p1.x * xq;
+              }
+            }
+          }
+#endif
+#ifdef PP_NO_PARAM
+        } else if (false) {
+#else
+        } else if (!updater && t + 1 < np) {
+#endif
+          // rotations of round t+1 from A_in and this round's rotations.  New pair = (second position of pair Ka,
+          // first position of pair Kb = Ka + 1) of this round; its off-diagonal entry is element [0][1] of the updated
+          // coupling block (rows of Kb, columns of Ka).
+          __builtin_amdgcn_s_setprio(3);   // the rotation chain is the round's critical path: issue ahead of the updaters on this SIMD
+          const int L = lane;
+          const int mtn = m + 1 - sg;                      // pairs of round t+1
+          const bool act = L < mtn;
+          const bool edge = (sg == 0) && (L == 0 || L == m);   // virtual pairs of a type-1 round
+          double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
+          if (act && !edge) {
+            const double* src = Ain + (sg == 0 ? (2 * L + 1) * lda + 2 * L - 1 : (2 * L + 2) * lda + 2 * L);
+            b00 = src[0]; b01 = src[1]; b10 = src[lda]; b11 = src[lda + 1];
+          }
+          const double cc_ = pc * pc, ss_ = ps * ps, sc2 = 2.0 * pc * ps * st_pq;
+          const double app1 = cc_ * st_pp - sc2 + ss_ * st_qq;    // lands on the pair's second position
+          const double aqq1 = ss_ * st_pp + sc2 + cc_ * st_qq;    // lands on the pair's first position
+          double npp, nqq, ccol, scol, crow, srow;
+          if (sg == 0) { npp = lane_prev(app1); nqq = aqq1; ccol = lane_prev(pc); scol = lane_prev(ps); crow = pc; srow = ps; }
+          else { npp = app1; nqq = lane_next(aqq1); ccol = pc; scol = ps; crow = lane_next(pc); srow = lane_next(ps); }
+          const double t01 = ccol * b00 - scol * b01, t11 = ccol * b10 - scol * b11;
+          double npq = srow * t01 + crow * t11;
+          if (sg == 0 && L == 0) npp = 0.0;
+          if (sg == 0 && L == m) nqq = 0.0;
+          if (!act) { npp = 0.0; nqq = 0.0; }
+          if (!act || edge) npq = 0.0;
+          double c = 1.0, sn = 0.0;
+          jacobi_cs(npp, nqq, npq, rot_thr, c, sn);
+          nrot += (sn != 0.0);
+          if (sg == 0 && L == 0) { c = 0.0; sn = -1.0; }
+          if (sg == 0 && L == m) { c = 0.0; sn = 1.0; }
+          if (act) *reinterpret_cast<double2*>(cs + (sg ^ 1) * csld + 2 * L) = make_double2(c, sn);
+          st_pp = npp; st_qq = nqq; st_pq = npq; pc = c; ps = sn;
+          __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+      };
+      for (int t = 0; t < np; t += 2) {
+        round(std::integral_constant<int, 0>{}, t);
+        round(std::integral_constant<int, 1>{}, t + 1);
+      }
+      ++sweeps;
+    }
+    // ---- eigenvalues back to the unshifted diagonal of A, eigenvectors (position order) to V
+    pofs = ((n & 1) && (sweeps & 1)) ? 1 : 0;
+    double dsave = 0.0;
+    if (tid < np) dsave = B0[(tid + 1) * lda + tid + 1];
+    __syncthreads();
+    if (tid < np) A[tid * lda + tid] = dsave;
+#pragma unroll
+    for (int j = 0; j < VRW; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        int r = j * UW + wv, col = 2 * lane + cc;
+        if (updater && r < np && col < np) V[r + (size_t)col * ldv] = vr[j][cc];
+      }
+    for (int idx = tid; idx < (npg - np) * np; idx += NT) { int r = np + idx / np, col = idx - (r - np) * np; V[r + (size_t)col * ldv] = 0.0; }
+    __syncthreads();
+  } else
+  if constexpr (SYS) {
+    // ---- register-resident systolic Jacobi.  The matrix (both triangles) and the eigenvectors live in VGPRs for all
+    // sweeps: lane J of every wave owns the column pair (2J, 2J+1); wave w owns the row pairs ("slots") I = w SPW + i
+    // of the matrix as 2x2 blocks ar[i][row][col], and rows w RPW + j of the eigenvector matrix.  Odd-even ordering:
+    // round type A rotates the position pairs (2J, 2J+1) - column and row rotations are register-local - and type B
+    // the pairs (2J+1, 2J+2): column partners come from the neighbouring lane over DPP (no LDS), row partners from the
+    // neighbouring slot (registers; across a wave boundary one row per wave through LDS).  Every rotation is followed
+    // by a swap of the two positions, so after np rounds every pair has met exactly once and the order is reversed.
+    // Per round: ONE workgroup barrier; LDS carries only the 2x2 rotation inputs and the boundary rows.
+    constexpr int NWV = NT / 64;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = half;
+    const int I0 = wv * SPW;
+    double ar[SPW][2][2];
+    double vr[RPW][2];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          int pr = 2 * (I0 + i) + rr, pc = 2 * lane + cc;
+          ar[i][rr][cc] = (pr < np && pc < np) ? A[sym_at(pr, pc, lda)] : 0.0;
+        }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        int r = wv * RPW + j, col = 2 * lane + cc;
+        double v = 0.0;
+        if (r < np && col < np) {
+          if (V_LDS) v = V[r + (size_t)col * ldv];
+          else if (r < n && col < n) v = warm ? V[r + (size_t)col * ldv] : (r == col ? 1.0 : 0.0);
+          else v = (r == col) ? 1.0 : 0.0;
+        }
+        vr[j][cc] = v;
+      }
+    __syncthreads();                       // A / V storage is dead from here until the write-back: exchange scratch
+    double* prm = A;                       // [2][65][4] = {B[2I][2I], B[2I+1][2I+1], B[2I][2I+1], B[2I+1][2I+2]} of slot I
+    double* halo = A + kSysPrm;            // [NWV][2][64][2]: first slot's row 0, last slot's row 1 of every wave
+    auto publish = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        const int I = I0 + i;
+        double* dst = prm + (buf * 65 + I) * 4;
+        if (lane == I) { dst[0] = ar[i][0][0]; dst[1] = ar[i][1][1]; dst[2] = ar[i][0][1]; }
+        if (lane == I + 1) dst[3] = ar[i][1][0];
+      }
+    };
+    // eigenvector columns: type A (x0, x1) <- (s x0 + c x1, c x0 - s x1); type B with the neighbours' columns
+    auto vrotA = [&](double c, double s) {
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        double x0 = vr[j][0], x1 = vr[j][1];
+        vr[j][0] = s * x0 + c * x1;
+        vr[j][1] = c * x0 - s * x1;
+      }
+    };
+    auto colB = [&](double& x0, double& x1, double c, double s, double cm, double sm) {
+      double xq = lane_next(x0), xp = lane_prev(x1);
+      double n1 = s * x1 + c * xq;       // position 2J+1: pair J = (own column 1, next lane's column 0)
+      double n0 = cm * xp - sm * x0;     // position 2J  : pair J-1 = (previous lane's column 1, own column 0)
+      x0 = n0; x1 = n1;
+    };
+    auto vrotB = [&](double c, double s, double cm, double sm) {
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) colB(vr[j][0], vr[j][1], c, s, cm, sm);
+    };
+    for (;;) {
+      double off2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        const bool dg = (lane == I0 + i);
+        off2 += ar[i][0][1] * ar[i][0][1] + ar[i][1][0] * ar[i][1][0];
+        if (!dg) off2 += ar[i][0][0] * ar[i][0][0] + ar[i][1][1] * ar[i][1][1];
+      }
+      off2 = block_sum(off2, red);
+      if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
+      publish(0);
+      __syncthreads();
+      // pending eigenvector update of the previous round (applied after the barrier so that it overlaps the next
+      // round's rotation set-up); starts as the identity of type B
+      double cB = 0.0, sB = 1.0, cmB = 0.0, smB = -1.0;
+      for (int t = 0; t < np; t += 2) {
+        double cA, sA;
+        {  // ===== round t, type A: pairs (2J, 2J+1)
+          const double2 dg = *reinterpret_cast<const double2*>(prm + lane * 4);
+          const double oa = prm[lane * 4 + 2];
+          jacobi_cs(dg.x, dg.y, oa, rot_thr, cA, sA);
+          if (lane >= m) { cA = 1.0; sA = 0.0; }
+          nrot += (sA != 0.0);
+          vrotB(cB, sB, cmB, smB);
+#pragma unroll
+          for (int i = 0; i < SPW; ++i) {
+            const int I = I0 + i;
+            const double cI = lane_bcast(cA, I), sI = lane_bcast(sA, I);
+            double t00 = sA * ar[i][0][0] + cA * ar[i][0][1], t01 = cA * ar[i][0][0] - sA * ar[i][0][1];
+            double t10 = sA * ar[i][1][0] + cA * ar[i][1][1], t11 = cA * ar[i][1][0] - sA * ar[i][1][1];
+            ar[i][0][0] = sI * t00 + cI * t10; ar[i][1][0] = cI * t00 - sI * t10;
+            ar[i][0][1] = sI * t01 + cI * t11; ar[i][1][1] = cI * t01 - sI * t11;
+            if (lane == I) { ar[i][0][1] = 0.0; ar[i][1][0] = 0.0; }
+          }
+          publish(1);
+          double* hw = halo + ((wv * 2) * 64 + lane) * 2;
+          *reinterpret_cast<double2*>(hw) = make_double2(ar[0][0][0], ar[0][0][1]);
+          *reinterpret_cast<double2*>(hw + 128) = make_double2(ar[SPW - 1][1][0], ar[SPW - 1][1][1]);
+          __syncthreads();
+        }
+        {  // ===== round t + 1, type B: pairs (2J+1, 2J+2); edge lanes / slots get the no-move parameters
+          const double app = prm[(65 + lane) * 4 + 1], aqq = prm[(65 + lane + 1) * 4], ob = prm[(65 + lane) * 4 + 3];
+          jacobi_cs(app, aqq, ob, rot_thr, cB, sB);
+          if (lane >= m - 1) { cB = 0.0; sB = 1.0; } else nrot += (sB != 0.0);
+          cmB = lane_prev(cB); smB = lane_prev(sB);
+          if (lane == 0) { cmB = 0.0; smB = -1.0; }
+          double hp0 = 0.0, hp1 = 0.0, hn0 = 0.0, hn1 = 0.0;
+          if (wv > 0) { double2 h = *reinterpret_cast<const double2*>(halo + (((wv - 1) * 2 + 1) * 64 + lane) * 2); hp0 = h.x; hp1 = h.y; }
+          if (wv < NWV - 1) { double2 h = *reinterpret_cast<const double2*>(halo + (((wv + 1) * 2) * 64 + lane) * 2); hn0 = h.x; hn1 = h.y; }
+          vrotA(cA, sA);
+          // columns
+#pragma unroll
+          for (int i = 0; i < SPW; ++i) {
+            colB(ar[i][0][0], ar[i][0][1], cB, sB, cmB, smB);
+            colB(ar[i][1][0], ar[i][1][1], cB, sB, cmB, smB);
+          }
+          colB(hp0, hp1, cB, sB, cmB, smB);
+          colB(hn0, hn1, cB, sB, cmB, smB);
+          // rows: pair I = (row 1 of slot I, row 0 of slot I + 1)
+          {
+            double cP = 0.0, sP = -1.0;
+            if (wv > 0) { cP = lane_bcast(cB, I0 - 1); sP = lane_bcast(sB, I0 - 1); }
+            ar[0][0][0] = cP * hp0 - sP * ar[0][0][0];
+            ar[0][0][1] = cP * hp1 - sP * ar[0][0][1];
+          }
+#pragma unroll
+          for (int i = 0; i < SPW; ++i) {
+            const int I = I0 + i;
+            const double cI = lane_bcast(cB, I), sI = lane_bcast(sB, I);
+            if (i + 1 < SPW) {
+#pragma unroll
+              for (int cc = 0; cc < 2; ++cc) {
+                double x = ar[i][1][cc], y = ar[i + 1][0][cc];
+                ar[i][1][cc] = sI * x + cI * y;
+                ar[i + 1][0][cc] = cI * x - sI * y;
+              }
+            } else {
+              ar[i][1][0] = sI * ar[i][1][0] + cI * hn0;
+              ar[i][1][1] = sI * ar[i][1][1] + cI * hn1;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < SPW; ++i) {
+            const int I = I0 + i;
+            if (lane == I + 1) ar[i][1][0] = 0.0;
+            if (lane == I - 1) ar[i][0][1] = 0.0;
+          }
+          publish(0);
+          __syncthreads();
+        }
+      }
+      vrotB(cB, sB, cmB, smB);
+      ++sweeps;
+    }
+    // ---- write back: eigenvalues to the diagonal of A, eigenvectors to V (position order); rows np .. npg-1 of the
+    // LDS copy are re-zeroed because the exchange scratch may have covered them
+    pofs = ((n & 1) && (sweeps & 1)) ? 1 : 0;   // an odd number of reversals leaves the padded index at position 0
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int I = I0 + i;
+      if (lane == I && I < m) { A[(2 * I) * lda + 2 * I] = ar[i][0][0]; A[(2 * I + 1) * lda + 2 * I + 1] = ar[i][1][1]; }
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        int r = wv * RPW + j, col = 2 * lane + cc;
+        if (V_LDS) { if (r < np && col < np) V[r + (size_t)col * ldv] = vr[j][cc]; }
+        else { int cg = col - pofs; if (r < n && col < np && cg >= 0 && cg < n) V[r + (size_t)cg * ldv] = vr[j][cc]; }
+      }
+    if (V_LDS)
+      for (int idx = tid; idx < (npg - np) * np; idx += NT) { int r = np + idx / np, col = idx - (r - np) * np; V[r + (size_t)col * ldv] = 0.0; }
+    __syncthreads();
+  } else
   if (BLOCK) {
     constexpr int NW = NT / 64;
     const int nb = npg >> 3, hb = nb >> 1, Mb = nb - 1, ntile = npg >> 4;
@@ -607,18 +1025,19 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 
   // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
   if (tid == 0) {
+    const int nl = (SYS || PP) ? np : n;   // positions that can hold an eigenvalue (the padded one is exactly 0: never selected)
     int npos = 0, nneg = 0;
-    for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; npos += (l > 0.0); nneg += (l < 0.0); }
+    for (int i = 0; i < nl; ++i) { double l = A[i * lda + i]; npos += (l > 0.0); nneg += (l < 0.0); }
     bool use_pos = npos <= nneg;
     int cnt = 0;
-    for (int i = 0; i < n; ++i) { double l = A[i * lda + i]; if (use_pos ? (l > 0.0) : (l < 0.0)) sel[cnt++] = i; }
+    for (int i = 0; i < nl; ++i) { double l = A[i * lda + i]; if (use_pos ? (l > 0.0) : (l < 0.0)) sel[cnt++] = i; }
     sel[npg] = cnt;
     sel[npg + 1] = use_pos ? 1 : 0;
   }
   __syncthreads();
   const int nsel = sel[npg];
   const bool use_pos = sel[npg + 1] != 0;
-  if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[tid * lda + tid];
+  if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[(tid + pofs) * lda + tid + pofs];
   const double kap = a.kappa ? *a.kappa : 1.0;
   double* wk = a.w + a.coff[k];
   double* nuw = a.nu + a.coff[k];
@@ -660,8 +1079,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
       for (int i = tid & 63; i < n; i += 64) {
         double s = 0.0;
         for (int t = 0; t < nsel; ++t) {
-          int l = sel[t];
-          s += A[l * lda + l] * V[i + (size_t)l * ldv] * V[j + (size_t)l * ldv];
+          int l = sel[t], lv = l - pofs;   // V in HBM is stored without the padded column
+          s += A[l * lda + l] * V[i + (size_t)lv * ldv] * V[j + (size_t)lv * ldv];
         }
         double nij = nuk[(size_t)j * n + i], nji = nuk[(size_t)i * n + j];
         if (!use_pos) s = 0.5 * (nij + nji) - s;
@@ -675,19 +1094,38 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   if (V_LDS) {
     double* vg = a.Vg + a.coff[k];
     for (int j = tid >> 6; j < n; j += NT >> 6)
-      for (int i = tid & 63; i < n; i += 64) vg[(size_t)j * n + i] = V[i + j * ldv];
+      for (int i = tid & 63; i < n; i += 64) vg[(size_t)j * n + i] = V[i + (j + pofs) * ldv];
   }
 #ifdef NNSDP_STAMPS
   if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
 #endif
 }
 
-// launch: NT = 1024 for blocks above kSmallBlock, 256 below
+// launch: projection algorithm by the largest block of the launch.
+//   kProjSystolic (default for 49 <= nmax <= 128): 512 threads, matrix + eigenvectors in registers
+//   kProjRoundRobin: LDS-resident round robin, NT = 1024 above kSmallBlock, 256 below (default for small blocks)
+//   kProjBlock: block Jacobi on MFMA (diagnostic; slower)
+enum { kProjRoundRobin = 0, kProjBlock = 1, kProjSystolic = 2, kProjPingPong = 3 };
 static constexpr int kSmallBlock = 40;
-inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, bool block = false) {
-  if (block && v_lds) {
-    if (nmax > kSmallBlock) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, true>), dim3(nblocks), dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((k_proj_jacobi<true, 256, true>), dim3(nblocks), dim3(256), lds, st, a);
+static constexpr int kSysMin = 49;
+inline bool proj_sys_ok(int nmax) { return nmax >= kSysMin && nmax <= 128; }
+inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   // V in LDS, 1024 threads
+#define NNSDP_PROJ_VARIANTS(X) \
+  X((k_proj_jacobi<true, 1024, 1>)) X((k_proj_jacobi<true, 256, 1>)) X((k_proj_jacobi<true, 1024>)) X((k_proj_jacobi<false, 1024>)) \
+  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<true, 1024, 3>))
+inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
+  if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
+    hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3>), dim3(nblocks), dim3(1024), lds, st, a);
+    return;
+  }
+  if (alg == kProjSystolic && proj_sys_ok(nmax)) {
+    if (v_lds) hipLaunchKernelGGL((k_proj_jacobi<true, 512, 2, 6, 12>), dim3(nblocks), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((k_proj_jacobi<false, 512, 2, 8, 16>), dim3(nblocks), dim3(512), lds, st, a);
+    return;
+  }
+  if (alg == kProjBlock && v_lds) {
+    if (nmax > kSmallBlock) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 1>), dim3(nblocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_proj_jacobi<true, 256, 1>), dim3(nblocks), dim3(256), lds, st, a);
     return;
   }
   if (nmax > kSmallBlock) {
@@ -699,30 +1137,33 @@ inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, si
   }
 }
 inline hipError_t proj_allow_big_lds() {
-  hipError_t e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_jacobi<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipSuccess;
+#define NNSDP_SET_LDS(K) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  NNSDP_PROJ_VARIANTS(NNSDP_SET_LDS)
+#undef NNSDP_SET_LDS
+  return e;
 }
 
-inline size_t proj_lds_bytes(int nmax, bool v_lds, bool block = false) {
+inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
   int np = (nmax + 15) & ~15;
+  if (alg == kProjSystolic) {
+    size_t am = ((size_t)np * (np + 1) + 1) & ~(size_t)1;
+    size_t d = am + (v_lds ? (size_t)np * (np + 1) : 0);
+    size_t scratch = (size_t)sys_scratch_doubles(8);
+    return (kSysHead + (d > scratch ? d : scratch)) * sizeof(double);
+  }
+  if (alg == kProjPingPong) {   // two bordered matrices (np + 2 rows, stride np + 3), rotation table, red, sel
+    size_t am = ((size_t)(np + 2) * (np + 3) + 1) & ~(size_t)1;
+    return (2 * am + 4 * (size_t)np + 16 + (np >> 1) + 2) * sizeof(double);
+  }
   size_t d = (size_t)np * (np + 1) + 1 + 16 + (np >> 1) + 2;           // A, red, sel[np+2] (ints)
   if (v_lds) d += (size_t)np * (np + 1);
-  if (block) d += (size_t)(np >> 4) * 272;                             // J + rotation parameters per block pair
+  if (alg == kProjBlock) d += (size_t)(np >> 4) * 272;                 // J + rotation parameters per block pair
   else d += 4 * (size_t)np;                                            // desc[2][half][4]
   return d * sizeof(double);
 }
 // block mode needs V in LDS and its scratch next to it
-inline bool proj_block_ok(int nmax) { return proj_lds_bytes(nmax, true, true) <= 160 * 1024; }
+inline bool proj_block_ok(int nmax) { return proj_lds_bytes(nmax, true, kProjBlock) <= 160 * 1024; }
 
 // ---------------------------------------------------------------------------------------------
 // multiplier block: w_s = max(nu_s, 0), reflection p = 2 w_s - nu_s - c   (also applies kappa)

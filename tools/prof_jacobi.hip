@@ -18,10 +18,14 @@ int main(int argc, char** argv) {
   hipMalloc(&dnu, h.size() * 8); hipMalloc(&dw, h.size() * 8); hipMalloc(&dV, h.size() * 8); hipMalloc(&dE, (8192 + batch * n) * 8);
   hipMemcpy(dcn, cn.data(), batch * 4, hipMemcpyHostToDevice); hipMemcpy(dco, coff.data(), (batch + 1) * 8, hipMemcpyHostToDevice);
   hipMemcpy(deo, eoff.data(), (batch + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(dnu, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-  bool blockmode = argc > 5 && atoi(argv[5]) && proj_block_ok(n);
-  bool v_lds = proj_lds_bytes(n, true) <= 160 * 1024; size_t lds = proj_lds_bytes(n, v_lds, blockmode);
+  int alg = argc > 5 ? atoi(argv[5]) : (proj_sys_ok(n) ? 2 : 0);   // 0 round robin (LDS), 1 block, 2 systolic (registers)
+  if (alg == 1 && !proj_block_ok(n)) alg = 0;
+  if (alg == 2 && !proj_sys_ok(n)) alg = 0;
+  if (alg == 3 && !proj_pp_ok(n)) alg = 0;
+  const bool blockmode = alg == 1;
+  bool v_lds = proj_lds_bytes(n, true, alg) <= 160 * 1024; size_t lds = proj_lds_bytes(n, v_lds, alg);
   proj_allow_big_lds();
-  ProjArgs a; a.cn = dcn; a.coff = dco; a.eoff = deo; a.nu = dnu; a.w = dw; a.Vg = dV; a.eig = dE; a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
+  ProjArgs a; a.cn = dcn; a.coff = dco; a.eoff = deo; a.nu = dnu; a.w = dw; a.Vg = dV; a.eig = dE; a.kappa = nullptr; a.tol_dev = nullptr; int* dstats; hipMalloc(&dstats, 16); a.stats = dstats; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; ++rep) {
     if (rep >= 2) {  // warm regime: perturb the matrices slightly, start from the stored eigenvectors, solver tolerance
@@ -31,10 +35,12 @@ int main(int argc, char** argv) {
       hipMemcpy(dnu, h.data(), h.size() * 8, hipMemcpyHostToDevice);
       a.warm = 1; a.tol = argc > 4 ? atof(argv[4]) : 1e-6;
     }
-    hipEventRecord(e0); launch_proj(a, batch, n, v_lds, lds, nullptr, blockmode); hipEventRecord(e1); hipDeviceSynchronize();
+    hipMemset(dstats, 0, 16);
+    hipEventRecord(e0); launch_proj(a, batch, n, v_lds, lds, nullptr, alg); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long dbg[70]; hipMemcpy(dbg, dE + 4096, sizeof(dbg), hipMemcpyDeviceToHost);
-    printf("n=%d batch=%d v_lds=%d kernel %.3f ms sweeps %lld -> %.1f us/sweep\n", n, batch, (int)v_lds, ms, dbg[64], 1e3 * ms / dbg[64]);
+    long long dbg[70] = {0}; hipMemcpy(dbg, dE + 4096, sizeof(dbg), hipMemcpyDeviceToHost);
+    int st[4]; hipMemcpy(st, dstats, 16, hipMemcpyDeviceToHost);
+    printf("n=%d batch=%d alg=%d v_lds=%d kernel %.3f ms, max sweeps %d (avg %.2f) -> %.1f us/sweep(max)\n", n, batch, alg, (int)v_lds, ms, st[1], (double)st[0] / batch, 1e3 * ms / (st[1] > 0 ? st[1] : 1));
 #ifdef NNSDP_STAMPS
     printf("  sections (cycles, wave 0): load+basis %lld  warm-GEMM %lld  sweeps %lld  reconstruct+store %lld\n", dbg[65], dbg[66], dbg[67], dbg[69]);
     if (rep != 1 && rep != 3) continue;
