@@ -548,7 +548,8 @@ struct nnsdp_solver {
   // inexact projections: Jacobi tolerance two orders below the current residual level
   void update_proj_tol() {
     if (opt.proj_tol > 0) return;
-    double t = std::min(1e-4, std::max(1e-9, 0.01 * std::max(last_pres, last_dres)));
+    static const double factor = [] { const char* e = std::getenv("NNSDP_PROJ_TOL_FACTOR"); return e ? std::atof(e) : 0.01; }();   // diagnostic override
+    double t = std::min(1e-4, std::max(1e-9, factor * std::max(last_pres, last_dres)));
     if (t < 0.5 * proj_tol || t > 2.0 * proj_tol) {
       proj_tol = t;
       HIPCHK(hipMemcpyAsync(scal.p + 2, &proj_tol, sizeof(double), hipMemcpyHostToDevice, st));

@@ -109,6 +109,48 @@ __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, do
   }
 }
 
+// same rotation plus its tangent t = s / c, for the scaled ("fast") rotations of the ping-pong sweeps.  Two Newton
+// steps on the hardware estimate (relative error <= 2^-23 -> 2^-45 -> below rounding), first-order renormalisation.
+__device__ __forceinline__ double rsqrt_nr2(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+__device__ __forceinline__ double rcp_nr2(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+__device__ __forceinline__ void jacobi_cst(double app, double aqq, double apq, double thr, double& c, double& s, double& t) {
+  c = 1.0; s = 0.0; t = 0.0;
+  if (fabs(apq) <= thr) return;
+  double d = aqq - app, b = 2.0 * apq;
+  double h2 = d * d + b * b;
+  if (apq != 0.0 && h2 > 1e-280 && h2 < 1e280) {
+    double rh = rsqrt_nr2(h2);
+    double u = 0.5 + 0.5 * fabs(d) * rh;     // in [0.5, 1]
+    double rc = rsqrt_nr2(u);                // 1/sqrt(u); rc^2 = 1/u
+    double sg = d < 0.0 ? -0.5 : 0.5;
+    double w = sg * b * rh * rc;
+    c = u * rc;
+    s = w;
+    t = w * rc * rc * rc * u;                // s / c = w / (u rc), with 1/u = rc^2
+    double nrm = 1.5 - 0.5 * (c * c + s * s);
+    c *= nrm; s *= nrm;
+  } else if (apq != 0.0) {
+    double sc = fmax(fabs(d), fabs(b));
+    double dd = d / sc, bb = b / sc;
+    double rh = 1.0 / sqrt(dd * dd + bb * bb);
+    double u = 0.5 + 0.5 * fabs(dd) * rh;
+    c = sqrt(u);
+    s = 0.5 * bb * rh / c;
+    if (d < 0.0) s = -s;
+    t = s / c;
+  }
+}
+
 // round-robin (chess tournament) schedule in closed form: index 0 stays in top slot 0, the other
 // np-1 indices sit on a cycle  t1 -> t2 -> ... -> t(h-1) -> b(h-1) -> ... -> b0 -> t1  and advance one
 // position per round.  Pair slot ia holds (top, bottom) = (pair_top, pair_bot) at round r.
@@ -152,6 +194,7 @@ __device__ __forceinline__ double lane_bcast(double x, int l) {
 // boundary rows halo[NW][2][64][2] exchanged between neighbouring waves
 static constexpr int kSysPrm = 2 * 65 * 4;
 __host__ __device__ constexpr int sys_scratch_doubles(int nw) { return kSysPrm + nw * 256; }
+static constexpr int kPpLda = 99;          // ping-pong variant: fixed stride of the bordered matrices (blocks up to 96)
 static constexpr int kSysHead = 16 + 66;   // red[16], sel[npg + 2 <= 130 ints] in front of A (fixed offsets)
 
 // BLOCK = true: block Jacobi.  Indices are grouped in blocks of 8; a round pairs the blocks (round robin),
@@ -165,7 +208,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   constexpr bool BLOCK = ALG == 1;
   constexpr bool SYS = ALG == 2;
   constexpr bool PP = ALG == 3;
-  static_assert(!PP || (V_LDS && NT == 1024), "ping-pong sweeps: V in LDS, 1024 threads");
+  static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
   const int k = blockIdx.x;
   const int n = a.cn[k];
@@ -173,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   const int npg = (n + 15) & ~15;  // storage / MFMA dimension (multiple of 16; zero rows, identity in V)
   const int half = np >> 1;
   constexpr bool PPL = ALG == 3;   // ping-pong sweeps keep a one-cell border around the matrix: 2 more rows / columns of storage
-  const int lda = PPL ? npg + 3 : npg + 1;   // odd stride (in doubles): column walks hit distinct banks
+  const int lda = PPL ? kPpLda : npg + 1;    // odd stride (in doubles): column walks hit distinct banks; a constant for the ping-pong variant (immediate LDS offsets)
   const int nrow = PPL ? npg + 2 : npg;      // rows of LDS storage per matrix
   const int tid = threadIdx.x;
   // systolic variant: reduction scratch and the selection list sit in FRONT of A at fixed offsets, because the sweeps
@@ -418,13 +461,19 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     // positions, so pairs are always neighbours and no index tables exist).  Round type 0 pairs (2K, 2K+1), type 1
     // pairs (2K-1, 2K) with virtual positions -1 and np at the ends; np rounds make every pair meet once and reverse
     // the order.  The lower triangle lives in LDS twice, shifted by one cell so that the virtual positions are a
-    // border of zeros and every 2x2 block of either round type is read and written unconditionally.  A round reads
-    // A_in and writes A_out (the eigenvector copy is not needed during the sweeps, its storage is the second buffer),
-    // so the LAST wave can compute round t+1's rotations from A_in - analytically for the two diagonal entries, from
-    // one 2x2 coupling block for the off-diagonal one - WHILE waves 0..14 apply round t.  One workgroup barrier per
-    // round.  Eigenvectors live in the registers of waves 0..14 (lane = column pair, neighbour columns over DPP).
+    // border and every 2x2 block of either round type is read and written unconditionally.  A round reads A_in and
+    // writes A_out (the eigenvector copy is not needed during the sweeps, its storage is the second buffer), so the
+    // LAST wave can compute round t+1's rotations from A_in - analytically for the two diagonal entries, from one 2x2
+    // coupling block for the off-diagonal one - WHILE waves 0..14 apply round t.  One workgroup barrier per round.
+    // Eigenvectors live in the registers of waves 0..14 (lane = column pair, neighbour columns over DPP).
+    // Rotations are applied in scaled form (square-root-free "fast" rotations): stored values are A_ij / (d_i d_j)
+    // and V_ij / d_j; with t = s/c the rotation + swap of positions (p, q) is
+    //     x_p' = x_q + (t d_p/d_q) x_p,   x_q' = x_p - (t d_q/d_p) x_q,   d_p' = c d_q,   d_q' = c d_p
+    // (2 FMAs per element pair instead of 4 operations; |theta| <= pi/4 keeps c >= 0.7, and one sweep shrinks a scale
+    // by at most 0.7^np, far inside the fp64 range).  The scales live in the parameter wave; the true values are
+    // restored at the end of every sweep, where convergence is measured.
     constexpr int UW = NT / 64 - 1;            // updater waves
-    constexpr int VRW = 7;                     // eigenvector rows per updater wave: 15 x 7 >= 96
+    constexpr int VRW = RPW;                   // eigenvector rows per updater wave (6: n <= 90, 7: n <= 96), dealt round robin
     constexpr int MAXI = 2;                    // items per updater thread: (m+1)(m+2)/2 <= 1225 <= 2 x 960
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,8 +481,14 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     const int m = half;
     double* const B0 = V;                      // shifted buffers: B0 holds the matrix at even rounds
     double* const B1 = A;
-    double* cs = desc;                         // [2][m + 2] x {c, s}
-    const int csld = 2 * (m + 2);
+    double* tt = desc;                         // [2][m + 2] x {t d_p/d_q, t d_q/d_p}; fixed entries for idle lanes / virtual pairs
+    const int ttld = 2 * (m + 2);
+    double* dsc = desc + 2 * ttld;             // [np] scale of every position at the end of a sweep
+    if (tid == 0) {
+      *reinterpret_cast<double2*>(tt + 2 * m) = make_double2(0.0, 0.0);
+      *reinterpret_cast<double2*>(tt + 2 * m + 2) = make_double2(0.0, 0.0);
+      *reinterpret_cast<double2*>(tt + ttld + 2 * m + 2) = make_double2(0.0, 0.0);
+    }
     // eigenvector rows -> registers (before the second matrix buffer overwrites the LDS copy)
     double vr[VRW][2];
 #pragma unroll
@@ -463,27 +518,30 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
       }
     }
     __syncthreads();
-    // shifted copy (lower triangle) with a border of zeros, then the border of the other buffer
+    // shifted copy (lower triangle) with a border of zeros; type-1 rounds read B1, whose border is never written
     for (int i = tid >> 6; i < np; i += NT >> 6)
       for (int j = tid & 63; j <= i; j += 64) B0[(i + 1) * lda + j + 1] = A[i * lda + j];
     for (int i = tid; i < np + 2; i += NT) { B0[i * lda] = 0.0; B0[(np + 1) * lda + i] = 0.0; }
     __syncthreads();
     for (int i = tid; i < np + 2; i += NT) { B1[i * lda] = 0.0; B1[(np + 1) * lda + i] = 0.0; }
-    // parameter wave state: (pp, qq, pq) of pair `lane` of the current round, its rotation (pc, ps)
-    double st_pp = 0.0, st_qq = 0.0, st_pq = 0.0, pc = 1.0, ps = 0.0;
+    // parameter wave state for pair `lane` of the current round: true (pp, qq, pq), rotation (pc, ps), scales of the
+    // pair's first / second position before the round
+    double st_pp = 0.0, st_qq = 0.0, st_pq = 0.0, pc = 1.0, ps = 0.0, st_dp = 1.0, st_dq = 1.0;
     for (;;) {
       double off2 = 0.0;
       for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
         for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[i * lda + j]; off2 += v * v; }
       off2 = 2.0 * block_sum(off2, red);
       if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
-      if (!updater) {   // rotations of round 0 (type 0) straight from the matrix
+      if (!updater) {   // rotations of round 0 (type 0) straight from the matrix, all scales 1
+        st_dp = 1.0; st_dq = 1.0;
         if (lane < m) {
           const double* d = B0 + (2 * lane + 1) * lda + 2 * lane + 1;
           st_pp = d[0]; st_qq = d[lda + 1]; st_pq = d[lda];
-          jacobi_cs(st_pp, st_qq, st_pq, rot_thr, pc, ps);
+          double t;
+          jacobi_cst(st_pp, st_qq, st_pq, rot_thr, pc, ps, t);
           nrot += (ps != 0.0);
-          *reinterpret_cast<double2*>(cs + 2 * lane) = make_double2(pc, ps);
+          *reinterpret_cast<double2*>(tt + 2 * lane) = make_double2(t, t);
         } else { st_pp = st_qq = st_pq = 0.0; pc = 1.0; ps = 0.0; }
       }
       __syncthreads();
@@ -491,108 +549,147 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
         constexpr int sg = decltype(sgc)::value;   // round type as a constant: the static item tables stay in registers
         const double* Ain = sg ? B1 : B0;
         double* Aout = sg ? B0 : B1;
-        const double* csr = cs + sg * csld;
+#ifdef NNSDP_STAMPS
+        long long tprev = clock64();
+#endif
+        const double* ttr = tt + sg * ttld;
 #ifdef PP_NO_UPDATE
         if (false) {
 #else
         if (updater) {
 #endif
-          // A_out <- M_r' A_in M_c on the lower block triangle, M = [s c; c -s] (rotation + swap)
-#ifndef PP_NO_A
-#pragma unroll
-          for (int u = 0; u < MAXI; ++u) {
-            const int it = ik[sg][u];
-            if (it >= 0) {
-              const int ka = it >> 8, kb = it & 255;
-              const double* src = Ain + eb[sg][u];
-              double* dst = Aout + eb[sg][u];
-              const double2 pr = *reinterpret_cast<const double2*>(csr + 2 * ka);
-              const double2 pq = *reinterpret_cast<const double2*>(csr + 2 * kb);
-              const double b00 = src[0], b10 = src[lda], b11 = src[lda + 1];
-              const double b01 = (ka == kb) ? b10 : src[1];
-              const double t00 = pq.y * b00 + pq.x * b01, t01 = pq.x * b00 - pq.y * b01;
-              const double t10 = pq.y * b10 + pq.x * b11, t11 = pq.x * b10 - pq.y * b11;
-              dst[0] = pr.y * t00 + pr.x * t10;
-              dst[lda] = pr.x * t00 - pr.y * t10;
-              dst[lda + 1] = pr.x * t01 - pr.y * t11;
-              if (ka != kb) dst[1] = pr.y * t01 + pr.x * t11;
-            }
+          // A_out <- M_r' A_in M_c on the lower block triangle, scaled rotation + swap.  Source order: LDS loads of
+          // the first block, eigenvector columns (registers; covers the LDS latency), block math and stores
+          auto blk_math = [&](int it, int ebo, double2 pr, double2 pq, double b00, double b01r, double b10, double b11) {
+            const bool dg = (it >> 8) == (it & 255);
+            double* dst = Aout + ebo;
+            const double b01 = dg ? b10 : b01r;
+            const double t00 = b01 + pq.x * b00, t01 = b00 - pq.y * b01;
+            const double t10 = b11 + pq.x * b10, t11 = b10 - pq.y * b11;
+            dst[0] = t10 + pr.x * t00;
+            dst[lda] = t00 - pr.y * t10;
+            dst[lda + 1] = t01 - pr.y * t11;
+            if (!dg) dst[1] = t11 + pr.x * t01;
+          };
+          const int it0 = ik[sg][0];
+          double2 pr0 = make_double2(0.0, 0.0), pq0 = pr0;
+          double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+          if (it0 >= 0) {
+            const double* src = Ain + eb[sg][0];
+            pr0 = *reinterpret_cast<const double2*>(ttr + 2 * (it0 >> 8));
+            pq0 = *reinterpret_cast<const double2*>(ttr + 2 * (it0 & 255));
+            a00 = src[0]; a01 = src[1]; a10 = src[lda]; a11 = src[lda + 1];
           }
-#endif
-#ifndef PP_NO_V
           // eigenvector columns (registers)
           if (sg == 0) {
-            const double2 p = *reinterpret_cast<const double2*>(csr + 2 * lane);
-            const double c = lane < m ? p.x : 1.0, sn = lane < m ? p.y : 0.0;
+            const double2 p = *reinterpret_cast<const double2*>(ttr + 2 * min(lane, m));
 #pragma unroll
             for (int j = 0; j < VRW; ++j) {
-              if (j * UW + wv < np) {
-                double x0 = vr[j][0], x1 = vr[j][1];
-                vr[j][0] = sn * x0 + c * x1;
-                vr[j][1] = c * x0 - sn * x1;
-              }
+              double x0 = vr[j][0], x1 = vr[j][1];
+              vr[j][0] = x1 + p.x * x0;
+              vr[j][1] = x0 - p.y * x1;
             }
-          } else {
-            // position 2J is the second of pair J = (2J-1, 2J); position 2J+1 the first of pair J+1
-            double2 p0 = *reinterpret_cast<const double2*>(csr + 2 * lane);
-            double2 p1 = *reinterpret_cast<const double2*>(csr + 2 * lane + 2);
-            if (lane >= m) { p0 = make_double2(0.0, -1.0); p1 = make_double2(0.0, 1.0); }
+          } else if (lane < m) {
+            // position 2J is the second of pair J = (2J-1, 2J), position 2J+1 the first of pair J+1; idle lanes are
+            // masked off, so the last real column reads 0 from its right-hand neighbour (DPP bound_ctrl)
+            const double2 p0 = *reinterpret_cast<const double2*>(ttr + 2 * lane);
+            const double2 p1 = *reinterpret_cast<const double2*>(ttr + 2 * lane + 2);
 #pragma unroll
             for (int j = 0; j < VRW; ++j) {
-              if (j * UW + wv < np) {
-                double x0 = vr[j][0], x1 = vr[j][1];
-                double xp = lane_prev(x1), xq = lane_next(x0);
-                vr[j][0] = p0.x * xp - p0.y * x0;
-                vr[j][1] = p1.y * x1 + p1.x * xq;
-              }
+              double x0 = vr[j][0], x1 = vr[j][1];
+              double xp = lane_prev(x1), xq = lane_next(x0);
+              vr[j][0] = xp - p0.y * x0;
+              vr[j][1] = xq + p1.x * x1;
             }
           }
-#endif
+          if (it0 >= 0) blk_math(it0, eb[sg][0], pr0, pq0, a00, a01, a10, a11);
+#pragma unroll
+          for (int u = 1; u < MAXI; ++u) {
+            const int it = ik[sg][u];
+            if (it >= 0) {
+              const double* src = Ain + eb[sg][u];
+              const double2 pr = *reinterpret_cast<const double2*>(ttr + 2 * (it >> 8));
+              const double2 pq = *reinterpret_cast<const double2*>(ttr + 2 * (it & 255));
+              blk_math(it, eb[sg][u], pr, pq, src[0], src[1], src[lda], src[lda + 1]);
+            }
+          }
 #ifdef PP_NO_PARAM
         } else if (false) {
 #else
-        } else if (!updater && t + 1 < np) {
+        } else if (!updater) {
 #endif
           // rotations of round t+1 from A_in and this round's rotations.  New pair = (second position of pair Ka,
           // first position of pair Kb = Ka + 1) of this round; its off-diagonal entry is element [0][1] of the updated
           // coupling block (rows of Kb, columns of Ka).
           __builtin_amdgcn_s_setprio(3);   // the rotation chain is the round's critical path: issue ahead of the updaters on this SIMD
           const int L = lane;
-          const int mtn = m + 1 - sg;                      // pairs of round t+1
-          const bool act = L < mtn;
-          const bool edge = (sg == 0) && (L == 0 || L == m);   // virtual pairs of a type-1 round
-          double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
-          if (act && !edge) {
-            const double* src = Ain + (sg == 0 ? (2 * L + 1) * lda + 2 * L - 1 : (2 * L + 2) * lda + 2 * L);
-            b00 = src[0]; b01 = src[1]; b10 = src[lda]; b11 = src[lda + 1];
+          const bool edge_cur = (sg == 1) && (L == 0 || L == m);     // virtual pairs keep their real position and scale
+          const double d1 = edge_cur ? st_dp : pc * st_dq;          // scales after this round: first / second position
+          const double d2 = edge_cur ? st_dq : pc * st_dp;
+          if (t + 1 < np) {
+            const int mtn = m + 1 - sg;                      // pairs of round t+1
+            const bool act = L < mtn;
+            const bool edge = (sg == 0) && (L == 0 || L == m);   // virtual pairs of a type-1 round
+            double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
+            if (act && !edge) {
+              const double* src = Ain + (sg == 0 ? (2 * L + 1) * lda + 2 * L - 1 : (2 * L + 2) * lda + 2 * L);
+              b00 = src[0]; b01 = src[1]; b10 = src[lda]; b11 = src[lda + 1];
+            }
+            const double cc_ = pc * pc, ss_ = ps * ps, sc2 = 2.0 * pc * ps * st_pq;
+            const double app1 = cc_ * st_pp - sc2 + ss_ * st_qq;    // lands on the pair's second position
+            const double aqq1 = ss_ * st_pp + sc2 + cc_ * st_qq;    // lands on the pair's first position
+            double npp, nqq, ndp, ndq, ccol, scol, dca, dcb, crow, srow, dra, drb;
+            if (sg == 0) {
+              npp = lane_prev(app1); nqq = aqq1; ndp = lane_prev(d2); ndq = d1;
+              ccol = lane_prev(pc); scol = lane_prev(ps); dca = lane_prev(st_dp); dcb = lane_prev(st_dq);
+              crow = pc; srow = ps; dra = st_dp; drb = st_dq;
+            } else {
+              npp = app1; nqq = lane_next(aqq1); ndp = d2; ndq = lane_next(d1);
+              ccol = pc; scol = ps; dca = st_dp; dcb = st_dq;
+              crow = lane_next(pc); srow = lane_next(ps); dra = lane_next(st_dp); drb = lane_next(st_dq);
+            }
+            const double e1 = ccol * dca, e2 = scol * dcb;
+            const double u01 = e1 * b00 - e2 * b01, u11 = e1 * b10 - e2 * b11;
+            double npq = (srow * dra) * u01 + (crow * drb) * u11;
+            if (sg == 0 && L == 0) { npp = 0.0; ndp = 1.0; }
+            if (sg == 0 && L == m) { nqq = 0.0; ndq = 1.0; }
+            if (!act) { npp = 0.0; nqq = 0.0; ndp = 1.0; ndq = 1.0; }
+            if (!act || edge) npq = 0.0;
+            const double rq = rcp_nr2(ndq), rp = rcp_nr2(ndp);
+            double c, sn, tg;
+            jacobi_cst(npp, nqq, npq, rot_thr, c, sn, tg);
+            nrot += (sn != 0.0);
+            double2 pub = make_double2(tg * ndp * rq, tg * ndq * rp);
+            if (sg == 0 && L == 0) { c = 0.0; sn = -1.0; pub = make_double2(0.0, -1.0); }
+            if (sg == 0 && L == m) { c = 0.0; sn = 1.0; pub = make_double2(1.0, 0.0); }
+            if (act) *reinterpret_cast<double2*>(tt + (sg ^ 1) * ttld + 2 * L) = pub;
+            st_pp = npp; st_qq = nqq; st_pq = npq; pc = c; ps = sn; st_dp = ndp; st_dq = ndq;
+          } else if (sg == 1) {
+            // last round of the sweep: publish the scale of every real position (pair L = positions 2L-1, 2L)
+            if (L >= 1 && L <= m) dsc[2 * L - 1] = d1;
+            if (L <= m - 1) dsc[2 * L] = d2;
           }
-          const double cc_ = pc * pc, ss_ = ps * ps, sc2 = 2.0 * pc * ps * st_pq;
-          const double app1 = cc_ * st_pp - sc2 + ss_ * st_qq;    // lands on the pair's second position
-          const double aqq1 = ss_ * st_pp + sc2 + cc_ * st_qq;    // lands on the pair's first position
-          double npp, nqq, ccol, scol, crow, srow;
-          if (sg == 0) { npp = lane_prev(app1); nqq = aqq1; ccol = lane_prev(pc); scol = lane_prev(ps); crow = pc; srow = ps; }
-          else { npp = app1; nqq = lane_next(aqq1); ccol = pc; scol = ps; crow = lane_next(pc); srow = lane_next(ps); }
-          const double t01 = ccol * b00 - scol * b01, t11 = ccol * b10 - scol * b11;
-          double npq = srow * t01 + crow * t11;
-          if (sg == 0 && L == 0) npp = 0.0;
-          if (sg == 0 && L == m) nqq = 0.0;
-          if (!act) { npp = 0.0; nqq = 0.0; }
-          if (!act || edge) npq = 0.0;
-          double c = 1.0, sn = 0.0;
-          jacobi_cs(npp, nqq, npq, rot_thr, c, sn);
-          nrot += (sn != 0.0);
-          if (sg == 0 && L == 0) { c = 0.0; sn = -1.0; }
-          if (sg == 0 && L == m) { c = 0.0; sn = 1.0; }
-          if (act) *reinterpret_cast<double2*>(cs + (sg ^ 1) * csld + 2 * L) = make_double2(c, sn);
-          st_pp = npp; st_qq = nqq; st_pq = npq; pc = c; ps = sn;
           __builtin_amdgcn_s_setprio(0);
         }
+        STAMP(sg * 2, tprev)
         __syncthreads();
+        STAMP(sg * 2 + 1, tprev)
       };
       for (int t = 0; t < np; t += 2) {
         round(std::integral_constant<int, 0>{}, t);
         round(std::integral_constant<int, 1>{}, t + 1);
       }
+      // back to true values: A_ij = d_i d_j a_ij, V_ij = d_j v_ij
+      for (int i = (tid >> 6) + 1; i <= np; i += NT >> 6) {
+        const double di = dsc[i - 1];
+        for (int j = (tid & 63) + 1; j <= i; j += 64) B0[i * lda + j] *= di * dsc[j - 1];
+      }
+      if (lane < m) {
+        const double da = dsc[2 * lane], db = dsc[2 * lane + 1];
+#pragma unroll
+        for (int j = 0; j < VRW; ++j) { vr[j][0] *= da; vr[j][1] *= db; }
+      }
+      __syncthreads();
       ++sweeps;
     }
     // ---- eigenvalues back to the unshifted diagonal of A, eigenvectors (position order) to V
@@ -1112,10 +1209,11 @@ inline bool proj_sys_ok(int nmax) { return nmax >= kSysMin && nmax <= 128; }
 inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   // V in LDS, 1024 threads
 #define NNSDP_PROJ_VARIANTS(X) \
   X((k_proj_jacobi<true, 1024, 1>)) X((k_proj_jacobi<true, 256, 1>)) X((k_proj_jacobi<true, 1024>)) X((k_proj_jacobi<false, 1024>)) \
-  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<true, 1024, 3>))
+  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>))
 inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
-    hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3>), dim3(nblocks), dim3(1024), lds, st, a);
+    if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 7>), dim3(nblocks), dim3(1024), lds, st, a);
     return;
   }
   if (alg == kProjSystolic && proj_sys_ok(nmax)) {
@@ -1152,8 +1250,8 @@ inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
     size_t scratch = (size_t)sys_scratch_doubles(8);
     return (kSysHead + (d > scratch ? d : scratch)) * sizeof(double);
   }
-  if (alg == kProjPingPong) {   // two bordered matrices (np + 2 rows, stride np + 3), rotation table, red, sel
-    size_t am = ((size_t)(np + 2) * (np + 3) + 1) & ~(size_t)1;
+  if (alg == kProjPingPong) {   // two bordered matrices (np + 2 rows, stride kPpLda), rotation table, red, sel
+    size_t am = ((size_t)(np + 2) * kPpLda + 1) & ~(size_t)1;
     return (2 * am + 4 * (size_t)np + 16 + (np >> 1) + 2) * sizeof(double);
   }
   size_t d = (size_t)np * (np + 1) + 1 + 16 + (np >> 1) + 2;           // A, red, sel[np+2] (ints)
