@@ -237,8 +237,42 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #ifdef NNSDP_STAMPS
   long long sec_t[6]; sec_t[0] = clock64();
 #endif
-  // ---- load: A = sym(nu_k) (full, both triangles, for the warm-start products), padded row/col zero
+  // ---- load: A = sym(nu_k) (full, both triangles, for the warm-start products), padded row/col zero; starting basis
   double fro2 = 0.0;
+  const bool warm = a.warm != 0;
+  if constexpr (PP) {
+    // every global load of the block (matrix, read ONCE and coalesced, and the warm basis) is issued before the
+    // first LDS store; the matrix is symmetrised in LDS afterwards
+    constexpr int JT = 6, IT = 2;   // 96 columns / 16 waves, 96 rows / 64 lanes
+    const int ln = tid & 63, wvi = tid >> 6;
+    const double* vgk = a.Vg + a.coff[k];
+    double ta[JT][IT], tv[JT][IT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj)
+#pragma unroll
+      for (int ii = 0; ii < IT; ++ii) {
+        const int j = wvi + 16 * jj, i = ln + 64 * ii;
+        const bool in = i < n && j < n;
+        ta[jj][ii] = in ? nuk[(size_t)j * n + i] : 0.0;
+        tv[jj][ii] = (warm && in) ? vgk[(size_t)j * n + i] : (i == j ? 1.0 : 0.0);
+      }
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj)
+#pragma unroll
+      for (int ii = 0; ii < IT; ++ii) {
+        const int j = wvi + 16 * jj, i = ln + 64 * ii;
+        if (i < npg && j < npg) { A[i * lda + j] = ta[jj][ii]; V[i + j * ldv] = tv[jj][ii]; }
+      }
+    __syncthreads();
+    for (int j = wvi; j < n; j += NT >> 6)
+      for (int i = ln + j + 1; i < n; i += 64) {
+        const double v = 0.5 * (A[i * lda + j] + A[j * lda + i]);
+        A[i * lda + j] = v; A[j * lda + i] = v;
+        fro2 += 2.0 * v * v;
+      }
+    if (tid < n) { const double v = A[tid * lda + tid]; fro2 += v * v; }
+    fro2 = block_sum(fro2, red);
+  } else {
   for (int j = tid >> 6; j < npg; j += NT >> 6)
     for (int i = tid & 63; i < npg; i += 64) {
       double v = 0.0;
@@ -248,7 +282,6 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     }
   fro2 = block_sum(fro2, red);
   // ---- starting basis
-  const bool warm = a.warm != 0;
   if (V_LDS) {
     for (int j = tid >> 6; j < npg; j += NT >> 6)
       for (int i = tid & 63; i < npg; i += 64) {
@@ -259,6 +292,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   } else if (!warm) {
     for (int j = tid >> 6; j < n; j += NT >> 6)
       for (int i = tid & 63; i < n; i += 64) V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
+  }
   }
   __syncthreads();
 #ifdef NNSDP_STAMPS
@@ -1121,15 +1155,27 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   if (a.stats && plane >= 0 && plane < half) { atomicAdd(&a.stats[2], nrot); atomicAdd(&a.stats[3], sweeps * M); }
 
   // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
-  if (tid == 0) {
+  {
+    // selection list in index order, built by two waves with ballots (positions 0..127)
     const int nl = (SYS || PP) ? np : n;   // positions that can hold an eigenvalue (the padded one is exactly 0: never selected)
-    int npos = 0, nneg = 0;
-    for (int i = 0; i < nl; ++i) { double l = A[i * lda + i]; npos += (l > 0.0); nneg += (l < 0.0); }
-    bool use_pos = npos <= nneg;
-    int cnt = 0;
-    for (int i = 0; i < nl; ++i) { double l = A[i * lda + i]; if (use_pos ? (l > 0.0) : (l < 0.0)) sel[cnt++] = i; }
-    sel[npg] = cnt;
-    sel[npg + 1] = use_pos ? 1 : 0;
+    int* cnt = reinterpret_cast<int*>(red);
+    const int ln = tid & 63, w2 = tid >> 6;
+    double l = 0.0;
+    if (tid < 128) {
+      if (tid < nl) l = A[tid * lda + tid];
+      const unsigned long long bp = __ballot(l > 0.0), bn = __ballot(l < 0.0);
+      if (ln == 0) { cnt[2 * w2] = __popcll(bp); cnt[2 * w2 + 1] = __popcll(bn); }
+    }
+    __syncthreads();
+    const int npos = cnt[0] + cnt[2], nneg = cnt[1] + cnt[3];
+    const bool up = npos <= nneg;
+    if (tid < 128) {
+      const bool me = up ? (l > 0.0) : (l < 0.0);
+      const unsigned long long mk = __ballot(me);
+      const int rank = __popcll(mk & ((1ull << ln) - 1ull)) + (w2 == 1 ? (up ? cnt[0] : cnt[1]) : 0);
+      if (me) sel[rank] = tid;
+    }
+    if (tid == 0) { sel[npg] = up ? npos : nneg; sel[npg + 1] = up ? 1 : 0; }
   }
   __syncthreads();
   const int nsel = sel[npg];
