@@ -481,7 +481,7 @@ struct nnsdp_solver {
   // Jacobi stops when off(A) <= 1e-8 |A|_F (measured directly): an inexact projection two orders below
   // the 1e-6 residual target; the certificate is checked independently at the end
   static constexpr double kProjTol = 1e-8;   // (fixed-tolerance fallback; the default is adaptive, see update_proj_tol)
-  static constexpr int kColdPeriod = 64;
+  static constexpr int kColdPeriod = 512;   // orthogonality of the warm basis drifts by ~n eps per iteration: 512 iterations stay below 1e-11
   static constexpr int kGraphIters = 8;
   bool next_is_warm() {
     bool warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     // A[l&15][l>>4], B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
     constexpr int NW = NT / 64;
     constexpr int MAXT = (NT == 512) ? 5 : 3;  // ceil(36 tiles / 16 waves), ceil(36 / 8), ceil(9 / 4)
-    const int nt = npg >> 4, ks = npg >> 2;
+    const int nt = npg >> 4, ks = (np + 3) >> 2;   // rows / columns past np are zero (identity in V): the K loop stops at np
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lc = lane >> 4;
     d4_t acc[MAXT];
