@@ -194,7 +194,8 @@ __device__ __forceinline__ double lane_bcast(double x, int l) {
 // boundary rows halo[NW][2][64][2] exchanged between neighbouring waves
 static constexpr int kSysPrm = 2 * 65 * 4;
 __host__ __device__ constexpr int sys_scratch_doubles(int nw) { return kSysPrm + nw * 256; }
-static constexpr int kPpLda = 99;          // ping-pong variant: fixed stride of the bordered matrices (blocks up to 96)
+static constexpr int kPpLda = 99;          // ping-pong variant: fixed stride of the MFMA-phase matrices (blocks up to 96; odd)
+static constexpr int kPpLdp = 100;         // ping-pong variant: stride of the sweep layout (even: aligned 16-byte row pairs)
 static constexpr int kSysHead = 16 + 66;   // red[16], sel[npg + 2 <= 130 ints] in front of A (fixed offsets)
 
 // BLOCK = true: block Jacobi.  Indices are grouped in blocks of 8; a round pairs the blocks (round robin),
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   // reuse the (then dead) A / V storage as exchange scratch whatever this block's own size is
   double* A = SYS ? lds + kSysHead : lds;
   // 2 buffers x half pair descriptors {c, s, (p, q), pad} = 4 doubles each, 16-byte aligned
-  double* desc = A + (((size_t)nrow * lda + 1) & ~(size_t)1);
+  double* desc = A + (PPL ? (size_t)nrow * kPpLdp : (((size_t)nrow * lda + 1) & ~(size_t)1));
   double* red = SYS ? lds : desc + (BLOCK ? 0 : 4 * npg);   // 16 doubles of reduction scratch (block mode: no pair descriptors)
   int* sel = reinterpret_cast<int*>(red + 16);  // npg + 2 ints: eigen-indices on the chosen side, counters
   double* V;
@@ -515,6 +516,12 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     const int m = half;
     double* const B0 = V;                      // shifted buffers: B0 holds the matrix at even rounds
     double* const B1 = A;
+    // Sweep layout of both buffers (stride kPpLdp, even): even rows first, then the odd rows, so that the two rows of a
+    // 2x2 block of EITHER round type are each one 16-byte aligned pair, read with one conflict-free ds_read_b128 per
+    // row (consecutive lanes = consecutive column pairs).  B0 is read by type-0 rounds (blocks start at odd shifted
+    // columns): its columns are stored one cell to the right; B1 is read by type-1 rounds (even columns): no shift.
+    const int H = m + 1;                       // rows per parity class (shifted indices 0 .. np + 1)
+    auto pidx = [&](int r, int c, int sh) { return ((r >> 1) + (r & 1) * H) * kPpLdp + c + sh; };
     double* tt = desc;                         // [2][m + 2] x {t d_p/d_q, t d_q/d_p}; fixed entries for idle lanes / virtual pairs
     const int ttld = 2 * (m + 2);
     double* dsc = desc + 2 * ttld;             // [np] scale of every position at the end of a sweep
@@ -548,30 +555,28 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
           else if (hi != row) v = (hi << 8) | (c - row - 1);
         }
         ik[sg][u] = v;
-        eb[sg][u] = (2 * (v >> 8) + 1 - sg) * lda + 2 * (v & 255) + 1 - sg;
+        eb[sg][u] = pidx(2 * (v >> 8) + 1 - sg, 2 * (v & 255) + 1 - sg, 1 - sg);   // in the buffer the round type READS
       }
     }
     __syncthreads();
     // shifted copy (lower triangle) with a border of zeros; type-1 rounds read B1, whose border is never written
     for (int i = tid >> 6; i < np; i += NT >> 6)
-      for (int j = tid & 63; j <= i; j += 64) B0[(i + 1) * lda + j + 1] = A[i * lda + j];
-    for (int i = tid; i < np + 2; i += NT) { B0[i * lda] = 0.0; B0[(np + 1) * lda + i] = 0.0; }
+      for (int j = tid & 63; j <= i; j += 64) B0[pidx(i + 1, j + 1, 1)] = A[i * lda + j];
     __syncthreads();
-    for (int i = tid; i < np + 2; i += NT) { B1[i * lda] = 0.0; B1[(np + 1) * lda + i] = 0.0; }
+    for (int i = tid; i < np + 2; i += NT) { B1[pidx(i, 0, 0)] = 0.0; B1[pidx(np + 1, i, 0)] = 0.0; }
     // parameter wave state for pair `lane` of the current round: true (pp, qq, pq), rotation (pc, ps), scales of the
     // pair's first / second position before the round
     double st_pp = 0.0, st_qq = 0.0, st_pq = 0.0, pc = 1.0, ps = 0.0, st_dp = 1.0, st_dq = 1.0;
     for (;;) {
       double off2 = 0.0;
       for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
-        for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[i * lda + j]; off2 += v * v; }
+        for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[pidx(i, j, 1)]; off2 += v * v; }
       off2 = 2.0 * block_sum(off2, red);
       if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
       if (!updater) {   // rotations of round 0 (type 0) straight from the matrix, all scales 1
         st_dp = 1.0; st_dq = 1.0;
         if (lane < m) {
-          const double* d = B0 + (2 * lane + 1) * lda + 2 * lane + 1;
-          st_pp = d[0]; st_qq = d[lda + 1]; st_pq = d[lda];
+          st_pp = B0[pidx(2 * lane + 1, 2 * lane + 1, 1)]; st_qq = B0[pidx(2 * lane + 2, 2 * lane + 2, 1)]; st_pq = B0[pidx(2 * lane + 2, 2 * lane + 1, 1)];
           double t;
           jacobi_cst(st_pp, st_qq, st_pq, rot_thr, pc, ps, t);
           nrot += (ps != 0.0);
@@ -594,15 +599,17 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #endif
           // A_out <- M_r' A_in M_c on the lower block triangle, scaled rotation + swap.  Source order: LDS loads of
           // the first block, eigenvector columns (registers; covers the LDS latency), block math and stores
+          const int rstep = sg ? H * kPpLdp : (1 - H) * kPpLdp;   // from the block's first row to its second (other parity class)
           auto blk_math = [&](int it, int ebo, double2 pr, double2 pq, double b00, double b01r, double b10, double b11) {
             const bool dg = (it >> 8) == (it & 255);
-            double* dst = Aout + ebo;
+            // the written buffer has the other column shift: same cells, one position to the left (type 0) / right (type 1)
+            double* dst = Aout + ebo + (sg ? 1 : -1);
             const double b01 = dg ? b10 : b01r;
             const double t00 = b01 + pq.x * b00, t01 = b00 - pq.y * b01;
             const double t10 = b11 + pq.x * b10, t11 = b10 - pq.y * b11;
             dst[0] = t10 + pr.x * t00;
-            dst[lda] = t00 - pr.y * t10;
-            dst[lda + 1] = t01 - pr.y * t11;
+            dst[rstep] = t00 - pr.y * t10;
+            dst[rstep + 1] = t01 - pr.y * t11;
             if (!dg) dst[1] = t11 + pr.x * t01;
           };
           const int it0 = ik[sg][0];
@@ -612,7 +619,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
             const double* src = Ain + eb[sg][0];
             pr0 = *reinterpret_cast<const double2*>(ttr + 2 * (it0 >> 8));
             pq0 = *reinterpret_cast<const double2*>(ttr + 2 * (it0 & 255));
-            a00 = src[0]; a01 = src[1]; a10 = src[lda]; a11 = src[lda + 1];
+            const double2 r0v = *reinterpret_cast<const double2*>(src), r1v = *reinterpret_cast<const double2*>(src + rstep);
+            a00 = r0v.x; a01 = r0v.y; a10 = r1v.x; a11 = r1v.y;
           }
           // eigenvector columns (registers)
           if (sg == 0) {
@@ -644,7 +652,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
               const double* src = Ain + eb[sg][u];
               const double2 pr = *reinterpret_cast<const double2*>(ttr + 2 * (it >> 8));
               const double2 pq = *reinterpret_cast<const double2*>(ttr + 2 * (it & 255));
-              blk_math(it, eb[sg][u], pr, pq, src[0], src[1], src[lda], src[lda + 1]);
+              const double2 r0v = *reinterpret_cast<const double2*>(src), r1v = *reinterpret_cast<const double2*>(src + rstep);
+              blk_math(it, eb[sg][u], pr, pq, r0v.x, r0v.y, r1v.x, r1v.y);
             }
           }
 #ifdef PP_NO_PARAM
@@ -666,8 +675,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
             const bool edge = (sg == 0) && (L == 0 || L == m);   // virtual pairs of a type-1 round
             double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
             if (act && !edge) {
-              const double* src = Ain + (sg == 0 ? (2 * L + 1) * lda + 2 * L - 1 : (2 * L + 2) * lda + 2 * L);
-              b00 = src[0]; b01 = src[1]; b10 = src[lda]; b11 = src[lda + 1];
+              const int r0 = sg == 0 ? 2 * L + 1 : 2 * L + 2, c0 = sg == 0 ? 2 * L - 1 : 2 * L, sh = 1 - sg;
+              b00 = Ain[pidx(r0, c0, sh)]; b01 = Ain[pidx(r0, c0 + 1, sh)]; b10 = Ain[pidx(r0 + 1, c0, sh)]; b11 = Ain[pidx(r0 + 1, c0 + 1, sh)];
             }
             const double cc_ = pc * pc, ss_ = ps * ps, sc2 = 2.0 * pc * ps * st_pq;
             const double app1 = cc_ * st_pp - sc2 + ss_ * st_qq;    // lands on the pair's second position
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
       // back to true values: A_ij = d_i d_j a_ij, V_ij = d_j v_ij
       for (int i = (tid >> 6) + 1; i <= np; i += NT >> 6) {
         const double di = dsc[i - 1];
-        for (int j = (tid & 63) + 1; j <= i; j += 64) B0[i * lda + j] *= di * dsc[j - 1];
+        for (int j = (tid & 63) + 1; j <= i; j += 64) B0[pidx(i, j, 1)] *= di * dsc[j - 1];
       }
       if (lane < m) {
         const double da = dsc[2 * lane], db = dsc[2 * lane + 1];
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     // ---- eigenvalues back to the unshifted diagonal of A, eigenvectors (position order) to V
     pofs = ((n & 1) && (sweeps & 1)) ? 1 : 0;
     double dsave = 0.0;
-    if (tid < np) dsave = B0[(tid + 1) * lda + tid + 1];
+    if (tid < np) dsave = B0[pidx(tid + 1, tid + 1, 1)];
     __syncthreads();
     if (tid < np) A[tid * lda + tid] = dsave;
 #pragma unroll
@@ -1297,7 +1306,7 @@ inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
     return (kSysHead + (d > scratch ? d : scratch)) * sizeof(double);
   }
   if (alg == kProjPingPong) {   // two bordered matrices (np + 2 rows, stride kPpLda), rotation table, red, sel
-    size_t am = ((size_t)(np + 2) * kPpLda + 1) & ~(size_t)1;
+    size_t am = (size_t)(np + 2) * kPpLdp;
     return (2 * am + 4 * (size_t)np + 16 + (np >> 1) + 2) * sizeof(double);
   }
   size_t d = (size_t)np * (np + 1) + 1 + 16 + (np >> 1) + 2;           // A, red, sel[np+2] (ints)
