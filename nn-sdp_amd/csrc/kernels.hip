@@ -439,9 +439,14 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
   sec_t[2] = clock64();
 #endif
   // ---- Jacobi sweeps (only the lower triangle of A is read and written from here on)
+  // (wave-uniform values are moved to scalar registers: the 1024-thread variants run at the 128-VGPR limit)
+  auto uniform = [](double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+  };
   const double tolv = a.tol_dev ? *a.tol_dev : a.tol;
-  const double thresh2 = tolv * tolv * fro2;  // converged when off(A) <= tol |A|_F, measured directly before each sweep
-  const double rot_thr = 0.5 * tolv * sqrt(fro2) / np;   // skipped elements together stay below tol/2
+  fro2 = uniform(fro2);
+  const double thresh2 = uniform(tolv * tolv * fro2);  // converged when off(A) <= tol |A|_F, measured directly before each sweep
+  const double rot_thr = uniform(0.5 * tolv * sqrt(fro2) / np);   // skipped elements together stay below tol/2
   int nrot = 0;
   const int plane = tid - (NT - 64);            // lane index inside the parameter wave (>= 0 there)
   const int M = np - 1;                         // rounds per sweep
@@ -566,7 +571,8 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
     for (int i = tid; i < np + 2; i += NT) { B1[pidx(i, 0, 0)] = 0.0; B1[pidx(np + 1, i, 0)] = 0.0; }
     // parameter wave state for pair `lane` of the current round: true (pp, qq, pq), rotation (pc, ps), scales of the
     // pair's first / second position before the round
-    double st_pp = 0.0, st_qq = 0.0, st_pq = 0.0, pc = 1.0, ps = 0.0, st_dp = 1.0, st_dq = 1.0;
+    // (the parameter wave holds no eigenvector rows: its state lives in those registers, the kernel runs at the VGPR limit)
+    double &st_pp = vr[0][0], &st_qq = vr[0][1], &st_pq = vr[1][0], &pc = vr[1][1], &ps = vr[2][0], &st_dp = vr[2][1], &st_dq = vr[3][0];
     for (;;) {
       double off2 = 0.0;
       for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
