@@ -163,6 +163,17 @@ int nnsdp_adjoint(const nnsdp_problem* p, const double* X, double* out);
 int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t decomp_mode,
                        int32_t* n_cliques, int32_t* total, int32_t* ptr, int32_t* idx);
 
+/* Interval pre-processing on the host: CROWN-sliced bounds of every hidden layer and
+ * the sector flags, the direct inputs of the assembler.  Replaces Intervals.intervalsAutoLirpaSliced
+ * (src/Intervals/intervals_auto_lirpa.jl:12-64; one PyCall + ONNX round trip per layer through
+ * exts/auto_lirpa_bridge.py:97-112) and makeSectorMinMax's interval test (src/Qc/activ_sector.jl:63-72, eps = 1e-4).
+ * K, xdims, M as in nnsdp_problem; acdim = xdims[1] + ... + xdims[K-1].  Outputs (caller-allocated, any may be NULL):
+ * acymin/acymax[acdim] post-activation bounds, acxmin/acxmax[acdim] pre-activation bounds, smin/smax[acdim] sector
+ * flags in {0,1}, ymin/ymax[xdims[K]] bounds of the network output.  No GPU needed. */
+int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const double* x1min, const double* x1max,
+                         double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
+                         double* ymin, double* ymax);
+
 /* Batched projection onto the PSD cone, the hot kernel (replaces the cone handling inside MOSEK;
  * reference of the arithmetic: LinearAlgebra.eigen on Symmetric).  mats: `batch` symmetric
  * matrices back to back, matrix b is n[b] x n[b] column-major, n[b] <= 128.  out receives the

@@ -16,6 +16,7 @@
 #include "../../include/nnsdp.h"
 #include "kernels.hip"
 #include "setup.hpp"
+#include "intervals.hpp"
 
 namespace nnsdp {
 
@@ -1060,6 +1061,30 @@ int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t mo
       for (int v : cl[k]) idx[o++] = v;
     }
     ptr[cl.size()] = o;
+  }
+  API_END
+}
+
+int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const double* x1min, const double* x1max,
+                         double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
+                         double* ymin, double* ymax) {
+  API_BEGIN
+  nnsdp::IntervalsOut iv = nnsdp::make_intervals(K, xdims, M, x1min, x1max);
+  const double eps = 1e-4;   // src/Qc/activ_sector.jl:65
+  size_t o = 0;
+  for (int k = 1; k < K; ++k)
+    for (int i = 0; i < xdims[k]; ++i, ++o) {
+      if (acymin) acymin[o] = iv.xlo[k][i];
+      if (acymax) acymax[o] = iv.xhi[k][i];
+      const double pl = iv.plo[k - 1][i], pu = iv.phi[k - 1][i];
+      if (acxmin) acxmin[o] = pl;
+      if (acxmax) acxmax[o] = pu;
+      if (smin) smin[o] = pl > eps ? 1.0 : 0.0;
+      if (smax) smax[o] = pu < -eps ? 0.0 : 1.0;
+    }
+  for (int i = 0; i < xdims[K]; ++i) {
+    if (ymin) ymin[i] = iv.xlo[K][i];
+    if (ymax) ymax[i] = iv.xhi[K][i];
   }
   API_END
 }

@@ -7,7 +7,8 @@
   findEllipsoid / findCircle / findReach2Dpoly            src/NnSdp.jl:35-95
   write_scale_csv           dump/scale column layout      experiments/scale.jl:60-82
 
-These run once per query on the host (numpy); the SDP itself goes through runQuery -> libnnsdp_hip.so.
+These run once per query on the host; the interval pre-processing is native C++ inside libnnsdp_hip.so
+(nnsdp_make_intervals, csrc/intervals.hpp), the SDP itself goes through runQuery -> libnnsdp_hip.so.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import methods as M
+from . import _lib
 
 
 # ----------------------------------------------------------------------------- f3: .nnet reader
@@ -49,69 +51,43 @@ def evalFeedFwdNet(net: M.FeedFwdNet, x) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- f1: CROWN-sliced intervals
-def _backward(Ws, bs, pre, lo, hi):
-    """backward LiRPA (CROWN) bounds of the last linear layer's output, float32 like the reference's
-    torch path; pre = pre-activation bounds of the earlier layers."""
-    f32 = np.float32
-    lA = uA = Ws[-1]
-    lb = ub = bs[-1]
-    for j in range(len(Ws) - 2, -1, -1):
-        l, u = pre[j]
-        lr = np.minimum(l, f32(0))
-        ur = np.maximum(np.maximum(u, f32(0)), lr + f32(1e-8))
-        du = ur / (ur - lr)                       # upper slope, intercept -lr*du
-        dl = (du > f32(0.5)).astype(f32)          # 'adaptive' lower slope
-        bu = -lr * du
-        lb = lb + np.minimum(lA, 0) @ bu
-        ub = ub + np.maximum(uA, 0) @ bu
-        lA = np.maximum(lA, 0) * dl + np.minimum(lA, 0) * du
-        uA = np.maximum(uA, 0) * du + np.minimum(uA, 0) * dl
-        lb = lb + lA @ bs[j]
-        ub = ub + uA @ bs[j]
-        lA = lA @ Ws[j]
-        uA = uA @ Ws[j]
-    c, r = (hi + lo) / f32(2), (hi - lo) / f32(2)
-    return (lA @ c - np.abs(lA) @ r + lb).astype(f32), (uA @ c + np.abs(uA) @ r + ub).astype(f32)
+def _intervals_native(x1min, x1max, net: M.FeedFwdNet):
+    """nnsdp_make_intervals (host C++ in the library, csrc/intervals.hpp): replaces the reference's per-layer
+    PyCall + ONNX + auto_LiRPA round trips (src/Intervals/intervals_auto_lirpa.jl:12-64)."""
+    lib = _lib.load()
+    xd = np.asarray(net.xdims, dtype=np.int32)
+    K = net.K
+    Mp = np.concatenate([np.asfortranarray(Mk, dtype=np.float64).ravel(order="F") for Mk in net.Ms])
+    lo = np.ascontiguousarray(x1min, dtype=np.float64)
+    hi = np.ascontiguousarray(x1max, dtype=np.float64)
+    if lo.shape != (xd[0],) or hi.shape != (xd[0],):
+        raise ValueError("x1min / x1max must have xdims[0] entries")
+    acdim = int(xd[1:-1].sum())
+    outs = [np.zeros(acdim) for _ in range(6)] + [np.zeros(int(xd[-1])) for _ in range(2)]
+    dp = _lib.c_double_p
+    _lib.check(lib.nnsdp_make_intervals(K, xd.ctypes.data_as(_lib.c_int32_p), Mp.ctypes.data_as(dp), lo.ctypes.data_as(dp),
+                                        hi.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in outs]))
+    return outs
 
 
 def makeIntervalsInfo(x1min, x1max, net: M.FeedFwdNet):
-    """returns (x_intvs, acx_intvs): K+1 post-activation intervals and K-1 pre-activation intervals."""
-    f32 = np.float32
-    x1min = np.asarray(x1min, dtype=np.float64)
-    x1max = np.asarray(x1max, dtype=np.float64)
-    W = [Mk[:, :-1].astype(f32) for Mk in net.Ms]
-    b = [Mk[:, -1].astype(f32) for Mk in net.Ms]
-    lo, hi = x1min.astype(f32), x1max.astype(f32)
-    x_intvs = [(x1min, x1max)]
-    pre = []
-    K = net.K
-
-    def fix(l, u):
-        l, u = l.astype(np.float64), u.astype(np.float64)
-        l = np.minimum(l, u)
-        return l, np.maximum(l, u)
-    for k in range(1, K):                 # slice k: layers 1..k followed by [I 0] (intervals_auto_lirpa.jl:12-28)
-        pre.append(_backward(W[:k], b[:k], pre, lo, hi))
+    """returns (x_intvs, acx_intvs): K+1 post-activation intervals and K-1 pre-activation intervals
+    (Intervals.makeIntervalsInfo with the sliced auto_LiRPA method, intervals_auto_lirpa.jl:31-64)."""
+    acymin, acymax, acxmin, acxmax, _, _, ymin, ymax = _intervals_native(x1min, x1max, net)
+    x_intvs = [(np.asarray(x1min, dtype=np.float64), np.asarray(x1max, dtype=np.float64))]
+    acx, o = [], 0
+    for k in range(1, net.K):
         n = net.xdims[k]
-        x_intvs.append(fix(*_backward(W[:k] + [np.eye(n, dtype=f32)], b[:k] + [np.zeros(n, dtype=f32)], pre, lo, hi)))
-    x_intvs.append(fix(*_backward(W, b, pre, lo, hi)))
-    acx = []
-    for k in range(K - 1):                # one float64 IBP step per layer (intervals_auto_lirpa.jl:55-62)
-        Wk, bk = net.Ms[k][:, :-1], net.Ms[k][:, -1]
-        l, u = x_intvs[k]
-        acx.append((np.maximum(Wk, 0) @ l + np.minimum(Wk, 0) @ u + bk, np.maximum(Wk, 0) @ u + np.minimum(Wk, 0) @ l + bk))
+        x_intvs.append((acymin[o:o + n], acymax[o:o + n]))
+        acx.append((acxmin[o:o + n], acxmax[o:o + n]))
+        o += n
+    x_intvs.append((ymin, ymax))
     return x_intvs, acx
 
 
 def makeQcActivs(net: M.FeedFwdNet, x1min, x1max, beta: int):
-    x_intvs, acx = makeIntervalsInfo(x1min, x1max, net)
-    acymin = np.concatenate([v[0] for v in x_intvs[1:-1]])
-    acymax = np.concatenate([v[1] for v in x_intvs[1:-1]])
-    amin = np.concatenate([v[0] for v in acx])
-    amax = np.concatenate([v[1] for v in acx])
-    eps = 1e-4                            # activ_sector.jl:65
-    smin = (amin > eps).astype(np.float64)
-    smax = 1.0 - (amax < -eps).astype(np.float64)
+    """Utils.makeQcActivs (src/Utils/qc.jl:6-24): bounded + sector QCs from the interval pre-processing."""
+    acymin, acymax, _, _, smin, smax, _, _ = _intervals_native(x1min, x1max, net)
     return [M.QcActivBounded(acymin=acymin, acymax=acymax),
             M.QcActivSector(acxdim=len(acymin), beta=int(beta), smin=smin, smax=smax)]
 

@@ -53,6 +53,48 @@ def test_intervals_and_qcs_match_fixture_and_oracle(name, beta):
         assert np.allclose(l, lo, rtol=0, atol=2e-6) and np.allclose(u, uo, rtol=0, atol=2e-6)
 
 
+def test_native_intervals_full_size_fixture():
+    # BASELINE configs[1]: W40-D20, 800 hidden neurons; native C++ pre-processing against the committed fixture
+    d = helpers.load_problem("W40-D20", 0)
+    net = na.FeedFwdNet(xdims=[int(v) for v in d["xdims"]], Ms=helpers.problem_Ms(d))
+    qb, qs = na.makeQcActivs(net, d["x1min"], d["x1max"], 0)
+    scale = np.maximum(1.0, np.abs(d["acymax"]))
+    assert np.max(np.abs(qb.acymin - d["acymin"]) / scale) < 1e-5 and np.max(np.abs(qb.acymax - d["acymax"]) / scale) < 1e-5
+    # sector flags may differ only where the pre-activation bound sits within float32 noise of the +-1e-4 threshold
+    assert np.mean(qs.smin != d["smin"]) < 0.005 and np.mean(qs.smax != d["smax"]) < 0.005
+
+
+def test_native_intervals_are_sound_on_ragged_net():
+    rng = np.random.default_rng(5)
+    xdims = [3, 7, 5, 9, 2]
+    Ms = [rng.standard_normal((xdims[k + 1], xdims[k] + 1)) * 0.7 for k in range(4)]
+    net = na.FeedFwdNet(xdims=xdims, Ms=Ms)
+    lo, hi = np.array([-0.3, 0.1, -1.0]), np.array([0.4, 0.5, -0.2])
+    x_intvs, acx = na.makeIntervalsInfo(lo, hi, net)
+    o = ointv.intervals_crown_sliced(nnet_io.FeedFwdNet(xdims=xdims, Ms=Ms), lo, hi)
+    for (l, u), (lo_, uo_) in zip(x_intvs, o.x_intvs):
+        assert np.allclose(l, lo_, atol=1e-5) and np.allclose(u, uo_, atol=1e-5)
+    for (l, u), (lo_, uo_) in zip(acx, o.acx_intvs):
+        assert np.allclose(l, lo_, atol=1e-5) and np.allclose(u, uo_, atol=1e-5)
+    X = lo[:, None] + (hi - lo)[:, None] * rng.random((3, 20000))
+    xk = X
+    for k in range(3):
+        pre = Ms[k][:, :-1] @ xk + Ms[k][:, -1:]
+        assert np.all(pre >= acx[k][0][:, None] - 1e-5) and np.all(pre <= acx[k][1][:, None] + 1e-5)
+        xk = np.maximum(pre, 0)
+        assert np.all(xk >= x_intvs[k + 1][0][:, None] - 1e-5) and np.all(xk <= x_intvs[k + 1][1][:, None] + 1e-5)
+    y = Ms[3][:, :-1] @ xk + Ms[3][:, -1:]
+    assert np.all(y >= x_intvs[4][0][:, None] - 1e-5) and np.all(y <= x_intvs[4][1][:, None] + 1e-5)
+
+
+def test_native_intervals_reject_bad_box():
+    net = na.FeedFwdNet(xdims=[2, 3, 2], Ms=[np.ones((3, 3)), np.ones((2, 4))])
+    with pytest.raises(RuntimeError):
+        na.makeIntervalsInfo([1.0, 0.0], [0.0, 1.0], net)
+    with pytest.raises(ValueError):
+        na.makeIntervalsInfo([0.0], [1.0], net)
+
+
 def test_scale_csv_layout(tmp_path):
     s = na.QuerySolution(objective_value=1.5, values={}, termination_status="OPTIMAL", total_time=3.0, setup_time=1.0,
                          solve_time=2.0, summary={"lambda_max": 1e-9})
