@@ -11,5 +11,9 @@ from .frontend import (  # noqa: F401
     findEllipsoid, findCircle, findReach2Dpoly, write_scale_csv,
 )
 from . import _lib  # noqa: F401
+from . import vnnlib  # noqa: F401
+from .vnnlib import (  # noqa: F401
+    read_vnnlib, hplaneS, loadVnnlibCnf, loadReluQueriesCnf, verifyAcasSpec, verifyPairs, isSolutionGood, shardPairs,
+)
 
 __version__ = "0.1.0"

@@ -1,0 +1,279 @@
+"""VNNLIB specifications and the CNF safety driver, host side.
+
+  read_vnnlib       the "simple" VNNLIB subset of ACAS-Xu style properties   exts/vnnlib_parser.jl:3-216
+  hplaneS           safety set  normal' y <= h  as the S matrix              src/Utils/qc.jl:27-37
+  loadVnnlibCnf     negated DNF property -> CNF of (input box, safety QC)    experiments/vnnlib_utils.jl:18-55
+  loadReluQueriesCnf  ... -> CNF of SafetyQuery                              experiments/vnnlib_utils.jl:58-74
+  verifyAcasSpec    clause-by-clause verification with early exit            experiments/acas.jl:76-137
+  verifyPairs       (network, spec) table, dump CSV layout                   experiments/acas.jl:139-187
+  shardPairs        load-balanced split of the pairs over ranks (multi-GPU: independent units, no collective)
+
+A VNNLIB file states the NEGATION of the property in disjunctive normal form:
+    NOT phi = OR_box OR_(A,b) (x in box AND A y <= b).
+The property holds iff every (box, A, b) case is refuted, and a case is refuted as soon as ONE row i is shown
+impossible on the box:  -A_i y <= -b_i - eps for all x in the box (eps = 1e-4, vnnlib_utils.jl:40-44).  So
+phi = AND_cases OR_rows safety(box, normal = -A_i, offset = -b_i - eps): a conjunction of disjunctive clauses, each
+sub-query one SDP through runQuery.
+"""
+from __future__ import annotations
+
+import csv
+import os
+import re
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import methods as M
+from . import frontend as F
+from . import parallel as P
+
+NSD_TOL = 1e-4          # experiments/acas.jl:71
+SPEC_EPS = 1e-4         # experiments/vnnlib_utils.jl:41
+
+
+# ----------------------------------------------------------------------------- parsing
+def _statements(text: str) -> List[Any]:
+    """s-expressions of the file (comments start at ';'), as nested lists of tokens."""
+    text = "\n".join(line.split(";", 1)[0] for line in text.splitlines())
+    toks = re.findall(r"\(|\)|[^\s()]+", text)
+    out, stack = [], []
+    for t in toks:
+        if t == "(":
+            stack.append([])
+        elif t == ")":
+            if not stack:
+                raise ValueError("vnnlib: unbalanced ')'")
+            done = stack.pop()
+            (stack[-1] if stack else out).append(done)
+        else:
+            if not stack:
+                raise ValueError(f"vnnlib: token {t!r} outside of a statement")
+            stack[-1].append(t)
+    if stack:
+        raise ValueError("vnnlib: unbalanced '('")
+    return out
+
+
+def _var(tok: str) -> Optional[Tuple[str, int]]:
+    m = re.fullmatch(r"([XY])_(\d+)", tok)
+    return (m.group(1), int(m.group(2))) if m else None
+
+
+@dataclass
+class _Case:
+    lo: np.ndarray
+    hi: np.ndarray
+    rows: List[np.ndarray]
+    rhs: List[float]
+
+    def copy(self):
+        return _Case(self.lo.copy(), self.hi.copy(), [r.copy() for r in self.rows], list(self.rhs))
+
+
+def _apply(case: _Case, cmp: Sequence[Any], nin: int, nout: int) -> None:
+    """one comparison (op a b): X bounds tighten the box, Y comparisons add a row  row' y <= rhs
+    (update_rv_tuple!, exts/vnnlib_parser.jl:46-96)."""
+    if len(cmp) != 3 or cmp[0] not in ("<=", ">=") or not all(isinstance(t, str) for t in cmp):
+        raise ValueError(f"vnnlib: unsupported comparison {cmp!r}")
+    op, a, b = cmp
+    va, vb = _var(a), _var(b)
+    if va and va[0] == "X":
+        if vb is not None:
+            raise ValueError("vnnlib: input constraints must compare X_i with a number")
+        i = va[1]
+        if not 0 <= i < nin:
+            raise ValueError(f"vnnlib: X_{i} out of range")
+        v = float(b)
+        if op == "<=":
+            case.hi[i] = min(case.hi[i], v)
+        else:
+            case.lo[i] = max(case.lo[i], v)
+        if case.lo[i] > case.hi[i]:
+            raise ValueError(f"vnnlib: empty interval for X_{i}")
+        return
+    if vb and vb[0] == "X":
+        raise ValueError("vnnlib: input constraints must have the variable first")
+    if op == ">=":
+        a, b, va, vb = b, a, vb, va
+    row, rhs = np.zeros(nout), 0.0
+    for v in (va, vb):
+        if v and not 0 <= v[1] < nout:
+            raise ValueError(f"vnnlib: Y_{v[1]} out of range")
+    if va and vb:
+        row[va[1]] += 1.0
+        row[vb[1]] -= 1.0
+    elif va:
+        row[va[1]] = 1.0
+        rhs = float(b)
+    elif vb:
+        row[vb[1]] = -1.0
+        rhs = -float(a)
+    else:
+        raise ValueError(f"vnnlib: comparison without a variable {cmp!r}")
+    case.rows.append(row)
+    case.rhs.append(rhs)
+
+
+def read_vnnlib(path_or_text: str, num_inputs: int, num_outputs: int):
+    """-> list of (box, specs): box = (lo, hi) arrays, specs = list of (A, b) with the unsafe set {y: A y <= b}.
+    Cases with the same input box are merged (read_vnnlib_simple, exts/vnnlib_parser.jl:106-216)."""
+    text = open(path_or_text).read() if os.path.exists(path_or_text) else path_or_text
+    cases = [_Case(np.full(num_inputs, -np.inf), np.full(num_inputs, np.inf), [], [])]
+    for st in _statements(text):
+        if not st:
+            continue
+        if st[0] == "declare-const":
+            continue
+        if st[0] != "assert" or len(st) != 2 or not isinstance(st[1], list):
+            raise ValueError(f"vnnlib: unsupported statement {st!r}")
+        body = st[1]
+        if body and body[0] in ("<=", ">="):
+            for c in cases:
+                _apply(c, body, num_inputs, num_outputs)
+            continue
+        if not body or body[0] != "or":
+            raise ValueError(f"vnnlib: unsupported assertion {body!r}")
+        alts = []
+        for alt in body[1:]:
+            if isinstance(alt, list) and alt and alt[0] == "and":
+                alts.append(alt[1:])
+            elif isinstance(alt, list) and alt and alt[0] in ("<=", ">="):
+                alts.append([alt])
+            else:
+                raise ValueError(f"vnnlib: unsupported disjunct {alt!r}")
+        new = []
+        for c in cases:
+            for alt in alts:
+                cc = c.copy()
+                for cmp in alt:
+                    _apply(cc, cmp, num_inputs, num_outputs)
+                new.append(cc)
+        cases = new
+    merged: Dict[bytes, Tuple[Tuple[np.ndarray, np.ndarray], list]] = {}
+    for c in cases:
+        if not (np.all(np.isfinite(c.lo)) and np.all(np.isfinite(c.hi))):
+            raise ValueError("vnnlib: every input needs a lower and an upper bound")
+        key = c.lo.tobytes() + c.hi.tobytes()
+        A = np.array(c.rows).reshape(len(c.rows), num_outputs)
+        merged.setdefault(key, ((c.lo, c.hi), []))[1].append((A, np.array(c.rhs)))
+    return list(merged.values())
+
+
+# ----------------------------------------------------------------------------- queries
+def hplaneS(normal, h: float, net: M.FeedFwdNet) -> np.ndarray:
+    """S of the safety set {normal' y <= h} on (x_1, y, 1): S23 = normal, S33 = -2h (src/Utils/qc.jl:27-37)."""
+    d1, dK = net.xdims[0], net.xdims[-1]
+    normal = np.asarray(normal, dtype=np.float64)
+    if normal.shape != (dK,):
+        raise ValueError("normal must have xdims[K] entries")
+    S = np.zeros((d1 + dK + 1, d1 + dK + 1))
+    S[d1:d1 + dK, -1] = normal
+    S[-1, d1:d1 + dK] = normal
+    S[-1, -1] = -2.0 * float(h)
+    return S
+
+
+def loadVnnlibCnf(spec, net: M.FeedFwdNet):
+    """CNF of (QcInputBox, QcSafety): one disjunctive clause per unsafe polytope, one literal per row."""
+    cnf = []
+    for (lo, hi), specs in read_vnnlib(spec, net.xdims[0], net.xdims[-1]):
+        qin = M.QcInputBox(x1min=lo, x1max=hi)
+        for A, b in specs:
+            if len(b) == 0:
+                raise ValueError("vnnlib: a case without output constraints is trivially violated")
+            cnf.append([(qin, M.QcSafety(S=hplaneS(-A[i], -b[i] - SPEC_EPS, net))) for i in range(len(b))])
+    return cnf
+
+
+def loadReluQueriesCnf(net: M.FeedFwdNet, spec, beta: int):
+    """CNF of SafetyQuery; the interval pre-processing runs once per input box (vnnlib_utils.jl:58-74)."""
+    if beta < 0:
+        raise ValueError("beta must be >= 0")
+    cache: Dict[bytes, Any] = {}
+    out = []
+    for clause in loadVnnlibCnf(spec, net):
+        qs = []
+        for qin, qsafe in clause:
+            key = np.asarray(qin.x1min).tobytes() + np.asarray(qin.x1max).tobytes()
+            if key not in cache:
+                cache[key] = F.makeQcActivs(net, qin.x1min, qin.x1max, beta)
+            qs.append(M.SafetyQuery(ffnet=net, qc_input=qin, qc_safety=qsafe, qc_activs=cache[key]))
+        out.append(qs)
+    return out
+
+
+def isSolutionGood(soln: M.QuerySolution) -> bool:
+    """experiments/acas.jl:76-79"""
+    if soln.termination_status == "OPTIMAL":
+        return True
+    lam = soln.summary.get("lambda_max") if soln.summary else None
+    if lam is None:
+        Z = np.asarray(soln.values["Z"])
+        lam = float(np.linalg.eigvalsh(0.5 * (Z + Z.T))[-1])
+    return bool(np.isfinite(lam) and lam <= NSD_TOL)
+
+
+def verifyAcasSpec(net: M.FeedFwdNet, spec, beta: int, opts: M.AdmmSdpOptions,
+                   solve: Callable[[Any, M.AdmmSdpOptions], M.QuerySolution] = None, log: Callable[[str], None] = None):
+    """Goes through the conjunction; a clause holds as soon as one of its sub-queries is certified, the spec fails as
+    soon as a clause has none (experiments/acas.jl:87-137).  -> (solutions tried, number of queries, status)."""
+    solve = solve or M.solveQuery
+    cnf = loadReluQueriesCnf(net, spec, beta)
+    num_queries = sum(len(c) for c in cnf)
+    solns, status = [], "safe"
+    for ci, clause in enumerate(cnf):
+        holds = False
+        for qi, q in enumerate(clause):
+            s = solve(q, opts)
+            solns.append(s)
+            good = isSolutionGood(s)
+            if log:
+                log(f"conj {ci + 1}/{len(cnf)} subquery {qi + 1}/{len(clause)}: {s.termination_status} "
+                    f"time {s.total_time:.3f}s lambda_max {s.summary.get('lambda_max', float('nan')):.3e} good={good}")
+            if good:
+                holds = True
+                break
+        if not holds:
+            status = "unsafe"
+            break
+    return solns, num_queries, status
+
+
+PAIR_COLUMNS = ["acas", "spec", "verif_status", "num_queries", "queries_ran", "avg_query_time", "total_time"]
+QUERY_COLUMNS = ["acas", "spec", "qnum", "num_queries", "time", "status", "eigmax"]
+
+
+def verifyPairs(pairs: Sequence[Tuple[str, M.FeedFwdNet, str, Any]], beta: int, opts: M.AdmmSdpOptions, saveto: str = None,
+                solve=None, log=None):
+    """pairs: (network name, network, spec name, spec path or text).  Writes the reference's two tables
+    (experiments/acas.jl:146-185): `saveto` and `saveto + "-qdf.csv"`, re-saved after every pair."""
+    rows, qrows = [], []
+    for name, net, sname, spec in pairs:
+        solns, nq, status = verifyAcasSpec(net, spec, beta, opts, solve=solve, log=log)
+        good = [s for s in solns if isSolutionGood(s)]
+        avg = sum(s.total_time for s in good) / len(good) if good else float("inf")
+        rows.append([name, sname, status, nq, len(solns), avg, sum(s.total_time for s in solns)])
+        for i, s in enumerate(solns):
+            qrows.append([name, sname, i + 1, nq, s.total_time, s.termination_status, s.summary.get("lambda_max", float("nan"))])
+        if saveto:
+            for path, cols, data in ((saveto, PAIR_COLUMNS, rows), (saveto + "-qdf.csv", QUERY_COLUMNS, qrows)):
+                with open(path, "w", newline="") as f:
+                    w = csv.writer(f)
+                    w.writerow(cols)
+                    w.writerows(data)
+    return rows, qrows
+
+
+def pairCost(net: M.FeedFwdNet, spec, beta: int, decomp_mode=M.SingleDecomp) -> float:
+    """work estimate of a (network, spec) pair: queries x sum of n_k^3 over the PSD blocks of one query."""
+    nq = sum(len(c) for c in loadVnnlibCnf(spec, net))
+    return float(nq) * float(sum(len(c) ** 3 for c in M.makeCliques(net.xdims, beta, decomp_mode)))
+
+
+def shardPairs(pairs, beta: int, world: int, rank: int, decomp_mode=M.SingleDecomp):
+    """the pairs this rank verifies: longest-processing-time bins over `world` ranks (BASELINE configs[4]: 'load-balanced
+    bins across 8 GPUs'); pairs are independent, so there is no data-path collective."""
+    costs = [pairCost(net, spec, beta, decomp_mode) for _, net, _, spec in pairs]
+    return [pairs[i] for i in P.bin_pack_by_cost(costs, world)[rank]]

@@ -160,3 +160,67 @@ def test_clique_sharded_iteration_matches_serial_gloo():
     for _ in range(40):
         S.step()
     assert np.abs(nu_sharded - S.nu).max() <= 1e-11 * max(1.0, np.abs(S.nu).max())
+
+
+# ----------------------------------------------------------------------------- f4: (network, spec) pairs over ranks
+def _oracle_safety_solver(query, opts):
+    """stands in for runQuery on ranks without a GPU: the oracle ADMM on the same query (checker side of the tests)."""
+    from oracle import admm as oadmm, nnet_io, operator as oop, qc as oqc
+    net = nnet_io.FeedFwdNet(xdims=list(query.ffnet.xdims), Ms=query.ffnet.Ms)
+    qs = query.qc_activs[1]
+    qo = oqc.make_safety_query(net, np.asarray(query.qc_input.x1min), np.asarray(query.qc_input.x1max), qs.beta, query.qc_safety.S)
+    r = oadmm.admm_solve(oop.build_operator(qo, "single", normalize=True), oadmm.AdmmOptions(max_iters=opts.max_iters))
+    import nnsdp_amd as na
+    ok = r.pres <= 1e-4 and r.dres <= 1e-4
+    return na.QuerySolution(float(r.objective), {}, "OPTIMAL" if ok else "ITERATION_LIMIT", 1.0, 0.1, 0.9,
+                            {"lambda_max": 1e-9 if ok else 1.0})
+
+
+def _pairs():
+    import nnsdp_amd as na
+    from oracle import nnet_io
+    spec = os.path.join(helpers.GOLDEN, "vnnlib", "prop_or_inputs.vnnlib")
+    nets = []
+    for seed, xd in ((1, [2, 6, 6, 2]), (2, [2, 8, 8, 8, 2]), (3, [2, 6, 6, 2]), (4, [2, 8, 8, 8, 2])):
+        n = nnet_io.random_net(xd, seed=seed)
+        nets.append((f"net{seed}", na.FeedFwdNet(xdims=list(n.xdims), Ms=n.Ms), "prop_or_inputs", spec))
+    return nets
+
+
+def _pair_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nnsdp_amd as na
+    from nnsdp_amd import vnnlib as vl
+    pairs = _pairs()
+    mine = vl.shardPairs(pairs, 0, world, rank)
+    rows, _ = vl.verifyPairs(mine, 0, na.AdmmSdpOptions(max_iters=1500), solve=_oracle_safety_solver)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [(r[0], r[2], r[3], r[4]) for r in rows])      # result table only
+    if rank == 0:
+        out.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vnnlib_pairs_sharded_over_two_ranks_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import nnsdp_amd as na
+    from nnsdp_amd import vnnlib as vl
+    serial, _ = vl.verifyPairs(_pairs(), 0, na.AdmmSdpOptions(max_iters=1500), solve=_oracle_safety_solver)
+    merged = sorted(x for part in gathered for x in part)
+    assert merged == sorted((r[0], r[2], r[3], r[4]) for r in serial)
+    assert all(len(part) == 2 for part in gathered)                                   # one heavy + one light pair per rank
