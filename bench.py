@@ -24,8 +24,8 @@ import time
 
 import numpy as np
 
-# the batched leg runs several independent SDPs on their own HIP streams; the default of 4 hardware queues would
-# serialise them (measured: 13 SDPs 9.9k -> 17.6k aggregate iterations/s with 16 queues).  Must be set before HIP starts.
+# the one-stream-per-SDP comparison of the batched leg needs more than the default 4 hardware queues (measured:
+# 13 SDPs 9.9k -> 17.6k aggregate iterations/s with 16 queues).  Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -204,21 +204,26 @@ def main():
                                       "ADMM primal/dual estimates. rho = objective of the polished point; lambda_max = eigmax(Z(gamma)) "
                                       "in the reference's coordinates (reference acceptance: 1e-6 .. 1e-4)")
     if rank == 0 and world == 1 and args.batch > 1 and not shard:
-        # the same kernels with `batch` independent SDPs side by side on one GPU (one HIP stream each)
+        # the same kernels with `batch` independent SDPs in lockstep on one GPU: batch handle (one launch per stage for
+        # all SDPs), and for comparison the older form with one HIP stream + hipGraph per SDP
         sb = na.SolverBatch([q] * args.batch, opts)
         sb.advance(args.burn_in)
-        sb.iterate(args.warmup)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        sb.iterate(args.steps)
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - tb
+        rates = {}
+        for name, fn in (("fused", sb.iterate), ("streams", sb.iterate_streams)):
+            fn(max(args.warmup, 16))
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            fn(args.steps)
+            torch.cuda.synchronize()
+            rates[name] = args.batch * args.steps / (time.perf_counter() - tb)
         sb.close()
-        agg = args.batch * args.steps / tb
+        agg = rates["fused"]
         out["batched"] = {"sdps": args.batch, "aggregate_iters_per_s": agg, "per_sdp_iters_per_s": agg / args.batch,
+                          "aggregate_iters_per_s_one_stream_per_sdp": rates["streams"],
                           "eig_TFLOPs_if_same_share": agg * float(sm["eig_flops_per_iter"]) / 1e12,
-                          "note": "independent SDPs (beta sweep of experiments/scale.jl:28, hyperplanes of findReach2Dpoly, ACAS sub-queries) side by side on one GPU, "
-                                  "one HIP stream + hipGraph replay per SDP; 13 x 19 blocks = 247 of the 256 CUs"}
+                          "eig_frac_of_fp64_peak_if_same_share": agg * float(sm["eig_flops_per_iter"]) / 1e12 / FP64_PEAK_TFLOPS,
+                          "note": "independent SDPs (beta sweep of experiments/scale.jl:28, hyperplanes of findReach2Dpoly, ACAS sub-queries) in lockstep on one GPU, "
+                                  "nnsdp_batch_*: one launch per stage for all SDPs, hipGraph replay; 13 x 19 blocks = 247 of the 256 CUs"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds)
     elif rank == 0:

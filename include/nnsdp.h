@@ -148,6 +148,21 @@ int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r);
 int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r);
 int nnsdp_solver_destroy(nnsdp_solver* s);
 
+/* Batch handle (no reference analogue): several independent SDPs - the beta sweep of experiments/scale.jl:28, the
+ * hyperplane directions of NnSdp.findReach2Dpoly (src/NnSdp.jl:73-95), the sub-queries of an ACAS clause
+ * (experiments/acas.jl:96-114) - advanced in lockstep with ONE kernel launch per stage for all of them.  The solvers
+ * stay owned by the caller and must outlive the batch; all on one device, not clique-sharded, same check_every.
+ *   nnsdp_batch_iterate  exactly `iters` plain iterations of every SDP (no checks, fixed penalty), synchronous
+ *   nnsdp_batch_run      full solves with the stopping rules of nnsdp_solve, each SDP on its own; status[count]
+ *                        receives the NNSDP_STATUS_* of every solver (collect results with nnsdp_solver_finish_status) */
+typedef struct nnsdp_batch nnsdp_batch;
+int nnsdp_batch_create(nnsdp_solver** solvers, int32_t count, nnsdp_batch** out);
+int nnsdp_batch_iterate(nnsdp_batch* b, int32_t iters);
+int nnsdp_batch_run(nnsdp_batch* b, int32_t* status);
+int nnsdp_batch_destroy(nnsdp_batch* b);
+/* result of a solver that stopped with `status` (as returned by nnsdp_batch_run): certificate polish, gamma, Z */
+int nnsdp_solver_finish_status(nnsdp_solver* s, int32_t status, nnsdp_result* r);
+
 /* Replaces Z = Zin + Zout + sum(Zacs) with numeric gamma: Qc.makeZin (src/Qc/input.jl:19-42),
  * makeZout (src/Qc/output.jl:52-106), makeZac (src/Qc/activ.jl:30-42).  gamma = [gin; gout; gac1; gac2]
  * (ngamma doubles); Z is Zdim x Zdim column-major.  Runs on the GPU. */

@@ -518,7 +518,8 @@ struct nnsdp_solver {
     int left = n;
     while (left > 0) {
       bool can_warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
-      if (!comm && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
+      static const bool no_graph = [] { const char* e = std::getenv("NNSDP_NO_GRAPH"); return e && std::atoi(e) != 0; }();   // diagnostic: eager launches only
+      if (!no_graph && !comm && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
         build_graph(kGraphIters);
         HIPCHK(hipGraphLaunch(gexec, st));
         since_cold += kGraphIters; iters_done += kGraphIters; left -= kGraphIters;
@@ -530,13 +531,17 @@ struct nnsdp_solver {
     if (sync) HIPCHK(hipStreamSynchronize(st));
   }
 
-  // one iteration with residual accumulation; fills last_*
-  void check_iteration() {
+  // one iteration with residual accumulation; fills last_*.  Split in two so that a batch handle can have the
+  // check iterations of several SDPs in flight on their streams at once.
+  double acc_host[8];
+  void check_enqueue() {
     enqueue_iteration(true, next_is_warm());
     ++iters_done;
-    double a[8];
-    HIPCHK(hipMemcpyAsync(a, acc.p, sizeof(a), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(acc_host, acc.p, sizeof(acc_host), hipMemcpyDeviceToHost, st));
+  }
+  void check_finish() {
     HIPCHK(hipStreamSynchronize(st));
+    const double* a = acc_host;
     double z0n = 0;  // |z0| (scaled) is 1 when normalised; compute anyway
     for (double v : S.z0) z0n += v * v;
     z0n = std::sqrt(z0n);
@@ -545,6 +550,7 @@ struct nnsdp_solver {
     last_pobj = a[5] / (S.zscale * S.cscale);
     last_dobj = a[6] / (S.zscale * S.cscale);
   }
+  void check_iteration() { check_enqueue(); check_finish(); }
 
   // inexact projections: Jacobi tolerance two orders below the current residual level
   void update_proj_tol() {
@@ -567,68 +573,77 @@ struct nnsdp_solver {
 
   // cap < 0: run to opt.max_iters with the stopping tests; cap >= 0: advance exactly `cap` more iterations with the
   // same checks and sigma / tolerance adaptation but without stopping (bench burn-in)
+  void loop_begin() {
+    if (next_adapt == 0) next_adapt = opt.adapt_every;
+    if (const char* e = std::getenv("NNSDP_TRACE_POLISH")) trace_polish = std::atoi(e);
+  }
+  // bookkeeping after a check iteration: projection tolerance, stopping tests, penalty adaptation.
+  // Returns a status to stop with, or -1 to go on.
+  int post_check(bool advance_only, double t0) {
+    if (opt.verbose)
+      std::fprintf(stderr, "[nnsdp] it %6lld pres %.3e dres %.3e obj %.8g dobj %.8g sigma %.3g\n", iters_done, last_pres,
+                   last_dres, last_pobj, last_dobj, sigma);
+    if (!(last_pres == last_pres) || !(last_dres == last_dres)) return NNSDP_STATUS_NUMERICAL_ERROR;
+    update_proj_tol();
+    if (trace_polish > 0 && iters_done >= next_trace) {
+      next_trace = iters_done + trace_polish;
+      double tp = now_s();
+      hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
+      HIPCHK(hipStreamSynchronize(st));
+      std::vector<double> gp = gs.download();
+      bool ok = polish(gp);
+      double o = 0.0;
+      for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
+      std::fprintf(stderr, "[nnsdp] it %6lld t %.2f polished rho %.8g (ok %d shift %.2e) admm %.8g dobj %.8g pres %.1e dres %.1e polish_ms %.0f\n", iters_done,
+                   now_s() - t0, o / (S.zscale * S.cscale), (int)ok, polish_shift, last_pobj, last_dobj, last_pres, last_dres, 1e3 * (now_s() - tp));
+    }
+    if (!advance_only && last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) return NNSDP_STATUS_OPTIMAL;
+    // optional early stop on the CERTIFIED objective: the polished point is exactly feasible, so once it
+    // is within cert_tol of the ADMM estimate of the optimum the certificate is as good as it gets
+    if (!advance_only && opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= 1e-3) {
+      next_cert = std::max<long long>(iters_done + 250, iters_done * 5 / 4);
+      hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
+      HIPCHK(hipStreamSynchronize(st));
+      std::vector<double> gp = gs.download();
+      if (polish(gp)) {
+        double o = 0.0;
+        for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
+        o /= (S.zscale * S.cscale);
+        double ref = std::max(std::fabs(last_pobj), std::fabs(last_dobj));
+        if (opt.verbose) std::fprintf(stderr, "[nnsdp] it %6lld certified rho %.8g  admm %.8g  dual %.8g\n", iters_done, o, last_pobj, last_dobj);
+        if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) {
+          return NNSDP_STATUS_OPTIMAL;
+        }
+      }
+    }
+    if (!advance_only && opt.max_time > 0 && now_s() - t0 > opt.max_time) return NNSDP_STATUS_TIME_LIMIT;
+    // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
+    {
+      double worst = std::max(last_pres, last_dres);
+      if (worst < 0.9 * best_res) { best_res = worst; best_iter = iters_done; }
+      else if (!advance_only && iters_done - best_iter >= 50000) return NNSDP_STATUS_SLOW_PROGRESS;
+    }
+    // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
+    if (opt.adapt_every > 0 && iters_done >= next_adapt) {
+      next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, iters_done * 3 / 2);
+      double ratio = std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
+      if (ratio > 1.5 || ratio < 0.67) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
+    }
+    return -1;
+  }
   int run_loop(long long cap = -1) {
     double t0 = now_s();
     int status = NNSDP_STATUS_ITERATION_LIMIT;
     const bool advance_only = cap >= 0;
     const long long limit = advance_only ? iters_done + cap : (long long)opt.max_iters;
     int ce = opt.check_every;
-    if (next_adapt == 0) next_adapt = opt.adapt_every;
-    if (const char* e = std::getenv("NNSDP_TRACE_POLISH")) trace_polish = std::atoi(e);
+    loop_begin();
     while (iters_done < limit) {
       int n = (int)std::min<long long>(ce - 1, limit - iters_done - 1);
       iterate(n, nullptr);
       check_iteration();
-      if (opt.verbose)
-        std::fprintf(stderr, "[nnsdp] it %6lld pres %.3e dres %.3e obj %.8g dobj %.8g sigma %.3g\n", iters_done, last_pres,
-                     last_dres, last_pobj, last_dobj, sigma);
-      if (!(last_pres == last_pres) || !(last_dres == last_dres)) { status = NNSDP_STATUS_NUMERICAL_ERROR; break; }
-      update_proj_tol();
-      if (trace_polish > 0 && iters_done >= next_trace) {
-        next_trace = iters_done + trace_polish;
-        double tp = now_s();
-        hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
-        HIPCHK(hipStreamSynchronize(st));
-        std::vector<double> gp = gs.download();
-        bool ok = polish(gp);
-        double o = 0.0;
-        for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
-        std::fprintf(stderr, "[nnsdp] it %6lld t %.2f polished rho %.8g (ok %d shift %.2e) admm %.8g dobj %.8g pres %.1e dres %.1e polish_ms %.0f\n", iters_done,
-                     now_s() - t0, o / (S.zscale * S.cscale), (int)ok, polish_shift, last_pobj, last_dobj, last_pres, last_dres, 1e3 * (now_s() - tp));
-      }
-      if (!advance_only && last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) { status = NNSDP_STATUS_OPTIMAL; break; }
-      // optional early stop on the CERTIFIED objective: the polished point is exactly feasible, so once it
-      // is within cert_tol of the ADMM estimate of the optimum the certificate is as good as it gets
-      if (!advance_only && opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= 1e-3) {
-        next_cert = std::max<long long>(iters_done + 250, iters_done * 5 / 4);
-        hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
-        HIPCHK(hipStreamSynchronize(st));
-        std::vector<double> gp = gs.download();
-        if (polish(gp)) {
-          double o = 0.0;
-          for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
-          o /= (S.zscale * S.cscale);
-          double ref = std::max(std::fabs(last_pobj), std::fabs(last_dobj));
-          if (opt.verbose) std::fprintf(stderr, "[nnsdp] it %6lld certified rho %.8g  admm %.8g  dual %.8g\n", iters_done, o, last_pobj, last_dobj);
-          if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) {
-            status = NNSDP_STATUS_OPTIMAL;
-            break;
-          }
-        }
-      }
-      if (!advance_only && opt.max_time > 0 && now_s() - t0 > opt.max_time) { status = NNSDP_STATUS_TIME_LIMIT; break; }
-      // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
-      {
-        double worst = std::max(last_pres, last_dres);
-        if (worst < 0.9 * best_res) { best_res = worst; best_iter = iters_done; }
-        else if (!advance_only && iters_done - best_iter >= 50000) { status = NNSDP_STATUS_SLOW_PROGRESS; break; }
-      }
-      // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
-      if (opt.adapt_every > 0 && iters_done >= next_adapt) {
-        next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, iters_done * 3 / 2);
-        double ratio = std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
-        if (ratio > 1.5 || ratio < 0.67) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
-      }
+      int st_ = post_check(advance_only, t0);
+      if (st_ >= 0) { status = st_; break; }
     }
     t_solve += now_s() - t0;
     return status;
@@ -860,6 +875,165 @@ struct nnsdp_solver {
 };
 
 // ------------------------------------------------------------------------------------------ ABI
+// ---------------------------------------------------------------------------------------------
+// Batch handle: several independent SDPs (beta sweep of experiments/scale.jl:28, hyperplane directions of
+// NnSdp.findReach2Dpoly, the sub-queries of an ACAS clause) advanced in lockstep with ONE launch per stage for all
+// of them - blockIdx.y (small kernels) or a block map (projection) selects the SDP.  A single W40-D20 SDP keeps
+// 19 of 256 CUs busy; one stream per SDP fills the chip only nominally, because every dependent launch of every
+// stream pays the queue-scheduling latency of 13 queues (measured: 13 streams reach 3.1x the single-SDP rate).
+// The solvers stay owned by the caller; plain iterations run through the batch, check iterations (one in
+// check_every) run on the solvers' own streams, all in flight together.
+// ---------------------------------------------------------------------------------------------
+struct nnsdp_batch {
+  std::vector<nnsdp_solver*> all;      // as given
+  std::vector<nnsdp_solver*> act;      // still iterating
+  std::vector<int> status;             // per solver of `all`, -1 while active
+  hipStream_t st = nullptr;
+  DBuf<IterArgs> d_it;
+  DBuf<ProjArgs> d_pw, d_pc;           // warm / cold projection arguments
+  DBuf<int2> d_map;
+  int nblocks = 0, nmax = 0, alg = 0;
+  bool v_lds = true;
+  size_t lds = 0;
+  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  static constexpr int kGraphIters = 8;
+
+  ~nnsdp_batch() {
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  void create(nnsdp_solver** sv, int count) {
+    if (!sv || count <= 0) throw std::invalid_argument("batch needs at least one solver");
+    for (int i = 0; i < count; ++i) {
+      if (!sv[i]) throw std::invalid_argument("null solver in batch");
+      if (sv[i]->comm) throw std::invalid_argument("clique-sharded solvers cannot be batched");
+      if (sv[i]->opt.device != sv[0]->opt.device) throw std::invalid_argument("batched solvers must live on one device");
+      if (sv[i]->opt.check_every != sv[0]->opt.check_every) throw std::invalid_argument("batched solvers must share check_every");
+      for (int j = 0; j < i; ++j) if (sv[j] == sv[i]) throw std::invalid_argument("a solver appears twice in the batch");
+      all.push_back(sv[i]);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    status.assign(count, -1);
+    act = all;
+    rebuild();
+  }
+
+  void rebuild() {
+    if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+    if (act.empty()) return;
+    std::vector<IterArgs> it;
+    std::vector<ProjArgs> pw, pc;
+    std::vector<int2> map;
+    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = 0;
+    for (size_t b = 0; b < act.size(); ++b) {
+      nnsdp_solver* s = act[b];
+      HIPCHK(hipStreamSynchronize(s->st));
+      s->since_cold = nnsdp_solver::kColdPeriod;   // lockstep: the next batched iteration is a cold one for everybody
+      IterArgs a;
+      a.ng = s->S.ng; a.NE = s->S.NE; a.ldm = s->ldm; a.nlong = s->nlong; a.nmat = s->nmat;
+      a.sptr = s->d_sptr.p; a.soff = s->d_soff.p; a.isdiag = s->d_isdiag.p;
+      a.csc_ptr = s->D.csc_ptr.p; a.csc_row = s->D.csc_row.p; a.csc_val = s->D.csc_val.p;
+      a.csr_ptr = s->D.csr_ptr.p; a.csr_col = s->D.csr_col.p; a.csr_val = s->D.csr_val.p;
+      a.longrows = s->d_long.p; a.gidx = s->d_gidx.p;
+      a.z0 = s->D.z0.p; a.Dinv = s->D.Dinv.p; a.c = s->D.c.p; a.Minv = s->Minv.p;
+      a.nu = s->nu.p; a.w = s->w.p; a.g = s->g.p; a.p = s->p.p; a.qv = s->qv.p; a.ww = s->ww.p; a.x = s->x.p;
+      a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
+      it.push_back(a);
+      ProjArgs q;
+      q.cn = s->d_cn.p; q.coff = s->d_coff.p; q.eoff = nullptr;
+      q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr;
+      q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
+      q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
+      q.warm = 1; pw.push_back(q);
+      q.warm = 0; pc.push_back(q);
+      for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));
+      nmax = std::max(nmax, s->nmax);
+      gx_gather = std::max(gx_gather, cdiv(a.NE, kThreads));
+      gx_at = std::max(gx_at, cdiv((long long)a.ng * 64, kThreads));
+      gx_gemv = gx_at;
+      gx_ax = std::max(gx_ax, cdiv((long long)a.NE * 16, kThreads));
+      gx_long = std::max(gx_long, a.nlong);
+      gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
+    }
+    nblocks = (int)map.size();
+    alg = proj_algorithm(nmax);
+    v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
+    lds = proj_lds_bytes(nmax, v_lds, alg);
+    if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
+    d_it.upload(it); d_pw.upload(pw); d_pc.upload(pc); d_map.upload(map);
+  }
+
+  void enqueue_iteration(bool warm) {
+    const int B = (int)act.size();
+    if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
+    hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_spmv_A_x_b, dim3(gx_ax, B), dim3(kThreads), 0, st, d_it.p);
+    if (gx_long > 0) hipLaunchKernelGGL(k_spmv_A_x_long_b, dim3(gx_long, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_update_nu_b, dim3(gx_upd, B), dim3(kThreads), 0, st, d_it.p);
+    HIPCHK(hipGetLastError());
+  }
+
+  // n plain iterations of every active solver (no residual checks, no adaptation); synchronous
+  void iterate(int n) {
+    if (n <= 0 || act.empty()) return;
+    int left = n;
+    while (left > 0) {
+      const int sc = act[0]->since_cold;   // equal for all active solvers
+      const bool warm_ok = act[0]->opt.warm_start != 0 && sc < nnsdp_solver::kColdPeriod;
+      int did;
+      if (warm_ok && left >= kGraphIters && nnsdp_solver::kColdPeriod - sc >= kGraphIters) {
+        if (!gexec) {
+          HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+          for (int i = 0; i < kGraphIters; ++i) enqueue_iteration(true);
+          HIPCHK(hipStreamEndCapture(st, &graph));
+          HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+        }
+        HIPCHK(hipGraphLaunch(gexec, st));
+        did = kGraphIters;
+      } else {
+        enqueue_iteration(warm_ok);
+        did = 1;
+      }
+      for (nnsdp_solver* s : act) {
+        s->iters_done += did;
+        s->since_cold = (did == 1 && !warm_ok) ? 1 : s->since_cold + did;
+      }
+      left -= did;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+  }
+
+  // full solves with the stopping rules of nnsdp_solver::run_loop, each SDP on its own
+  void run() {
+    double t0 = now_s();
+    for (nnsdp_solver* s : act) s->loop_begin();
+    while (!act.empty()) {
+      long long n = act[0]->opt.check_every - 1;
+      for (nnsdp_solver* s : act) n = std::min<long long>(n, (long long)s->opt.max_iters - s->iters_done - 1);
+      iterate((int)std::max<long long>(n, 0));
+      for (nnsdp_solver* s : act) s->check_enqueue();
+      for (nnsdp_solver* s : act) s->check_finish();
+      std::vector<nnsdp_solver*> keep;
+      for (nnsdp_solver* s : act) {
+        int stt = s->post_check(false, t0);
+        if (stt < 0 && s->iters_done >= s->opt.max_iters) stt = NNSDP_STATUS_ITERATION_LIMIT;
+        if (stt >= 0) {
+          for (size_t i = 0; i < all.size(); ++i) if (all[i] == s) status[i] = stt;
+          s->t_solve += now_s() - t0;
+        } else keep.push_back(s);
+      }
+      if (keep.size() != act.size()) { act = keep; rebuild(); }
+    }
+  }
+};
+
 #define API_BEGIN try {
 #define API_END                                                                    \
   }                                                                                \
@@ -987,6 +1161,14 @@ int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r) {
   API_BEGIN
   if (!s || !r) throw std::invalid_argument("null argument");
   int status = (s->last_pres <= s->opt.eps_rel && s->last_dres <= s->opt.eps_rel) ? NNSDP_STATUS_OPTIMAL : NNSDP_STATUS_ITERATION_LIMIT;
+  s->finish(r, status);
+  API_END
+}
+
+int nnsdp_solver_finish_status(nnsdp_solver* s, int32_t status, nnsdp_result* r) {
+  API_BEGIN
+  if (!s || !r) throw std::invalid_argument("null argument");
+  if (status < NNSDP_STATUS_OPTIMAL || status > NNSDP_STATUS_NUMERICAL_ERROR) throw std::invalid_argument("unrecognized status");
   s->finish(r, status);
   API_END
 }
@@ -1130,6 +1312,38 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   if (kernel_ms) *kernel_ms = ms;
   HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
   if (eigvals) HIPCHK(hipMemcpy(eigvals, dE.p, etot * sizeof(double), hipMemcpyDeviceToHost));
+  API_END
+}
+
+int nnsdp_batch_create(nnsdp_solver** solvers, int32_t count, nnsdp_batch** out) {
+  API_BEGIN
+  if (!out) throw std::invalid_argument("null argument");
+  require_gpu();
+  std::unique_ptr<nnsdp_batch> b(new nnsdp_batch());
+  b->create(solvers, count);
+  *out = b.release();
+  API_END
+}
+
+int nnsdp_batch_iterate(nnsdp_batch* b, int32_t iters) {
+  API_BEGIN
+  if (!b) throw std::invalid_argument("null batch");
+  if (iters < 0) throw std::invalid_argument("iters must be >= 0");
+  b->iterate(iters);
+  API_END
+}
+
+int nnsdp_batch_run(nnsdp_batch* b, int32_t* status) {
+  API_BEGIN
+  if (!b) throw std::invalid_argument("null batch");
+  b->run();
+  if (status) for (size_t i = 0; i < b->all.size(); ++i) status[i] = b->status[i];
+  API_END
+}
+
+int nnsdp_batch_destroy(nnsdp_batch* b) {
+  API_BEGIN
+  delete b;
   API_END
 }
 

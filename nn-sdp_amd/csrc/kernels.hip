@@ -205,13 +205,12 @@ static constexpr int kSysHead = 16 + 66;   // red[16], sel[npg + 2 <= 130 ints] 
 // ALG = 2: register-resident systolic sweeps (below).  SPW = pair slots (2 matrix rows each) per wave, RPW = eigenvector
 // rows per wave; NT/64 * SPW >= ceil(n/2) and NT/64 * RPW >= n + 1 for every block of the launch.
 template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
-__global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
+__device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   constexpr bool BLOCK = ALG == 1;
   constexpr bool SYS = ALG == 2;
   constexpr bool PP = ALG == 3;
   static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
-  const int k = blockIdx.x;
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // Jacobi dimension (even)
   const int npg = (n + 15) & ~15;  // storage / MFMA dimension (multiple of 16; zero rows, identity in V)
@@ -1259,6 +1258,16 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
 #endif
 }
 
+template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
+__global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) { proj_body<V_LDS, NT, ALG, SPW, RPW>(a, blockIdx.x); }
+// one launch for the blocks of SEVERAL independent SDPs: map[blockIdx.x] = (SDP, block of that SDP)
+template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
+__global__ __launch_bounds__(NT) void k_proj_jacobi_b(const ProjArgs* __restrict__ args, const int2* __restrict__ map) {
+  const int2 m = map[blockIdx.x];
+  const ProjArgs a = args[m.x];
+  proj_body<V_LDS, NT, ALG, SPW, RPW>(a, m.y);
+}
+
 // launch: projection algorithm by the largest block of the launch.
 //   kProjSystolic (default for 49 <= nmax <= 128): 512 threads, matrix + eigenvectors in registers
 //   kProjRoundRobin: LDS-resident round robin, NT = 1024 above kSmallBlock, 256 below (default for small blocks)
@@ -1270,7 +1279,9 @@ inline bool proj_sys_ok(int nmax) { return nmax >= kSysMin && nmax <= 128; }
 inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   // V in LDS, 1024 threads
 #define NNSDP_PROJ_VARIANTS(X) \
   X((k_proj_jacobi<true, 1024, 1>)) X((k_proj_jacobi<true, 256, 1>)) X((k_proj_jacobi<true, 1024>)) X((k_proj_jacobi<false, 1024>)) \
-  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>))
+  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>)) \
+  X((k_proj_jacobi_b<true, 1024>)) X((k_proj_jacobi_b<false, 1024>)) X((k_proj_jacobi_b<true, 256>)) X((k_proj_jacobi_b<false, 256>)) \
+  X((k_proj_jacobi_b<true, 512, 2, 6, 12>)) X((k_proj_jacobi_b<false, 512, 2, 8, 16>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 6>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 7>))
 inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
     if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
@@ -1293,6 +1304,27 @@ inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, si
   } else {
     if (v_lds) hipLaunchKernelGGL((k_proj_jacobi<true, 256>), dim3(nblocks), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((k_proj_jacobi<false, 256>), dim3(nblocks), dim3(256), lds, st, a);
+  }
+}
+// batched form: `nblocks` blocks in total over the SDPs of a batch handle (device arrays args / map)
+inline void launch_proj_batched(const ProjArgs* dargs, const int2* dmap, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st,
+                                int alg) {
+  if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
+    if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
+    else hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 7>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
+    return;
+  }
+  if (alg == kProjSystolic && proj_sys_ok(nmax)) {
+    if (v_lds) hipLaunchKernelGGL((k_proj_jacobi_b<true, 512, 2, 6, 12>), dim3(nblocks), dim3(512), lds, st, dargs, dmap);
+    else hipLaunchKernelGGL((k_proj_jacobi_b<false, 512, 2, 8, 16>), dim3(nblocks), dim3(512), lds, st, dargs, dmap);
+    return;
+  }
+  if (nmax > kSmallBlock) {
+    if (v_lds) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
+    else hipLaunchKernelGGL((k_proj_jacobi_b<false, 1024>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
+  } else {
+    if (v_lds) hipLaunchKernelGGL((k_proj_jacobi_b<true, 256>), dim3(nblocks), dim3(256), lds, st, dargs, dmap);
+    else hipLaunchKernelGGL((k_proj_jacobi_b<false, 256>), dim3(nblocks), dim3(256), lds, st, dargs, dmap);
   }
 }
 inline hipError_t proj_allow_big_lds() {
@@ -1324,16 +1356,31 @@ inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
 // block mode needs V in LDS and its scratch next to it
 inline bool proj_block_ok(int nmax) { return proj_lds_bytes(nmax, true, kProjBlock) <= 160 * 1024; }
 
+// everything one plain ADMM iteration of one SDP needs besides the projection (batch handles: one launch per stage
+// for all SDPs, blockIdx.y = SDP)
+struct IterArgs {
+  int ng, NE, ldm, nlong;
+  long long nmat;
+  const int* sptr; const long long* soff; const unsigned char* isdiag;
+  const int* csc_ptr; const int* csc_row; const double* csc_val;
+  const int* csr_ptr; const int* csr_col; const double* csr_val;
+  const int* longrows; const unsigned int* gidx;
+  const double* z0; const double* Dinv; const double* c; const double* Minv;
+  double* nu; double* w; double* g; double* p; double* qv; double* ww; double* x;
+  const double* sigma; double* kappa;
+  double alpha;
+};
+
 // ---------------------------------------------------------------------------------------------
 // multiplier block: w_s = max(nu_s, 0), reflection p = 2 w_s - nu_s - c   (also applies kappa)
 // fused into the A' product: qv[g] = sum_e A[e,g] gvec[e] - p[g]; one wave per multiplier.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_spmv_At(int ng, const int* __restrict__ ptr, const int* __restrict__ row,
+__device__ __forceinline__ void spmv_At_body(const int bid, int ng, const int* __restrict__ ptr, const int* __restrict__ row,
                                                        const double* __restrict__ val, const double* __restrict__ gvec,
                                                        double* __restrict__ nus, const double* __restrict__ c,
                                                        const double* __restrict__ kappa, double* __restrict__ p,
                                                        double* __restrict__ qv) {
-  int g = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  int g = (bid * kThreads + threadIdx.x) >> 6;
   int lane = threadIdx.x & 63;
   if (g >= ng) return;
   double s = 0.0;
@@ -1348,19 +1395,39 @@ __global__ __launch_bounds__(kThreads) void k_spmv_At(int ng, const int* __restr
     qv[g] = s - pp;
   }
 }
+__global__ __launch_bounds__(kThreads) void k_spmv_At(int ng, const int* __restrict__ ptr, const int* __restrict__ row,
+                                                       const double* __restrict__ val, const double* __restrict__ gvec,
+                                                       double* __restrict__ nus, const double* __restrict__ c,
+                                                       const double* __restrict__ kappa, double* __restrict__ p,
+                                                       double* __restrict__ qv) { spmv_At_body(blockIdx.x, ng, ptr, row, val, gvec, nus, c, kappa, p, qv); }
+__global__ __launch_bounds__(kThreads) void k_spmv_At_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  if ((long long)blockIdx.x * kThreads >= (long long)a.ng * 64) return;
+  spmv_At_body(blockIdx.x, a.ng, a.csc_ptr, a.csc_row, a.csc_val, a.g, a.nu, a.c, a.kappa, a.p, a.qv);
+}
 
 // g[e] = Dinv[e] (z0[e] / sigma + wgt * sum_src (2 w - nu)[src]); one thread per pattern entry
-__global__ __launch_bounds__(kThreads) void k_gather_g(int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
+__device__ __forceinline__ void gather_g_body(const int bid, int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
                                                         const unsigned char* __restrict__ isdiag,
                                                         const double* __restrict__ nuk, const double* __restrict__ wk,
                                                         const double* __restrict__ z0, const double* __restrict__ Dinv,
                                                         const double* __restrict__ sigma, double* __restrict__ g) {
-  int e = blockIdx.x * kThreads + threadIdx.x;
+  int e = bid * kThreads + threadIdx.x;
   if (e >= NE) return;
   double s = 0.0;
   for (int q = sptr[e]; q < sptr[e + 1]; ++q) { long long o = soff[q]; s += 2.0 * wk[o] - nuk[o]; }
   if (!isdiag[e]) s *= kSqrt2;
   g[e] = Dinv[e] * (z0[e] / (*sigma) + s);
+}
+__global__ __launch_bounds__(kThreads) void k_gather_g(int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
+                                                        const unsigned char* __restrict__ isdiag,
+                                                        const double* __restrict__ nuk, const double* __restrict__ wk,
+                                                        const double* __restrict__ z0, const double* __restrict__ Dinv,
+                                                        const double* __restrict__ sigma, double* __restrict__ g) { gather_g_body(blockIdx.x, NE, sptr, soff, isdiag, nuk, wk, z0, Dinv, sigma, g); }
+__global__ __launch_bounds__(kThreads) void k_gather_g_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  if ((long long)blockIdx.x * kThreads >= (long long)a.NE) return;
+  gather_g_body(blockIdx.x, a.NE, a.sptr, a.soff, a.isdiag, a.nu + a.ng, a.w + a.ng, a.z0, a.Dinv, a.sigma, a.g);
 }
 
 // clique-sharded mode: h[e] = wgt * sum over the rank's OWN sources of (2 w - nu), or of (nu - w) when dual != 0;
@@ -1387,9 +1454,9 @@ __global__ __launch_bounds__(kThreads) void k_finish_g(int NE, const double* __r
 }
 
 // ww = Minv qv  (Minv symmetric, column-major): one wave per output row, coalesced column reads
-__global__ __launch_bounds__(kThreads) void k_gemv_sym(int n, int ldm, const double* __restrict__ Minv, const double* __restrict__ x,
+__device__ __forceinline__ void gemv_sym_body(const int bid, int n, int ldm, const double* __restrict__ Minv, const double* __restrict__ x,
                                                         double* __restrict__ y) {
-  int i = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  int i = (bid * kThreads + threadIdx.x) >> 6;
   int lane = threadIdx.x & 63;
   if (i >= n) return;
   const double* col = Minv + (size_t)i * ldm;  // ldm even: 16-byte aligned columns
@@ -1405,14 +1472,21 @@ __global__ __launch_bounds__(kThreads) void k_gemv_sym(int n, int ldm, const dou
   double s = wave_sum(s0 + s1);
   if (lane == 0) y[i] = s;
 }
+__global__ __launch_bounds__(kThreads) void k_gemv_sym(int n, int ldm, const double* __restrict__ Minv, const double* __restrict__ x,
+                                                        double* __restrict__ y) { gemv_sym_body(blockIdx.x, n, ldm, Minv, x, y); }
+__global__ __launch_bounds__(kThreads) void k_gemv_sym_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  if ((long long)blockIdx.x * kThreads >= (long long)a.ng * 64) return;
+  gemv_sym_body(blockIdx.x, a.ng, a.ldm, a.Minv, a.qv, a.ww);
+}
 
 // x[e] = g[e] - Dinv[e] * sum_g A[e,g] ww[g]; 16 lanes per pattern entry
 static constexpr int kLongRow = 256;   // rows of A with more nonzeros go to the block-per-row kernel
-__global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __restrict__ ptr, const int* __restrict__ col,
+__device__ __forceinline__ void spmv_A_x_body(const int bid, int NE, const int* __restrict__ ptr, const int* __restrict__ col,
                                                         const double* __restrict__ val, const double* __restrict__ ww,
                                                         const double* __restrict__ g, const double* __restrict__ Dinv,
                                                         double* __restrict__ x) {
-  int e = (blockIdx.x * kThreads + threadIdx.x) >> 4;
+  int e = (bid * kThreads + threadIdx.x) >> 4;
   int sub = threadIdx.x & 15;
   double s = 0.0;
   bool mine = e < NE && ptr[e + 1] - ptr[e] <= kLongRow;
@@ -1422,23 +1496,41 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __rest
   for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
   if (mine && sub == 0) x[e] = g[e] - Dinv[e] * s;
 }
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __restrict__ ptr, const int* __restrict__ col,
+                                                        const double* __restrict__ val, const double* __restrict__ ww,
+                                                        const double* __restrict__ g, const double* __restrict__ Dinv,
+                                                        double* __restrict__ x) { spmv_A_x_body(blockIdx.x, NE, ptr, col, val, ww, g, Dinv, x); }
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  if ((long long)blockIdx.x * kThreads >= (long long)a.NE * 16) return;
+  spmv_A_x_body(blockIdx.x, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+}
 
 // the few long rows (the affine-affine entry touches every multiplier): one workgroup per row
-__global__ __launch_bounds__(kThreads) void k_spmv_A_x_long(int nlong, const int* __restrict__ rows, const int* __restrict__ ptr,
+__device__ __forceinline__ void spmv_A_x_long_body(const int bid, int nlong, const int* __restrict__ rows, const int* __restrict__ ptr,
                                                              const int* __restrict__ col, const double* __restrict__ val,
                                                              const double* __restrict__ ww, const double* __restrict__ g,
                                                              const double* __restrict__ Dinv, double* __restrict__ x) {
   __shared__ double red[8];
-  int e = rows[blockIdx.x];
+  int e = rows[bid];
   double s = 0.0;
   for (int q = ptr[e] + threadIdx.x; q < ptr[e + 1]; q += kThreads) s += val[q] * ww[col[q]];
   s = block_sum(s, red);
   if (threadIdx.x == 0) x[e] = g[e] - Dinv[e] * s;
 }
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_long(int nlong, const int* __restrict__ rows, const int* __restrict__ ptr,
+                                                             const int* __restrict__ col, const double* __restrict__ val,
+                                                             const double* __restrict__ ww, const double* __restrict__ g,
+                                                             const double* __restrict__ Dinv, double* __restrict__ x) { spmv_A_x_long_body(blockIdx.x, nlong, rows, ptr, col, val, ww, g, Dinv, x); }
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_long_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  if ((long long)blockIdx.x * kThreads >= (long long)a.nlong * kThreads) return;
+  spmv_A_x_long_body(blockIdx.x, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+}
 
 // nu <- nu + alpha (K x + q - w).  acc (may be null) accumulates at check iterations:
 //   acc[0] += |Kx+q-w|^2, acc[1] += |Kx+q|^2, acc[2] += |w|^2
-__global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, const double* __restrict__ p,
+__device__ __forceinline__ void update_nu_body(const int bid, int ng, long long nmat, const double* __restrict__ p,
                                                          const double* __restrict__ ww, const double* __restrict__ c,
                                                          const double* __restrict__ x, const unsigned int* __restrict__ gidx,
                                                          double* __restrict__ nu, const double* __restrict__ w,
@@ -1447,7 +1539,7 @@ __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, 
   // [lo, hi): the clique elements this rank owns (everything when not sharded); acc_s: count the
   // multiplier block in the residual sums (rank 0 only when sharded, the sums are all-reduced)
   __shared__ double red[8];
-  long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  long long i = (long long)bid * kThreads + threadIdx.x;
   double r2 = 0.0, k2 = 0.0, w2 = 0.0;
   if (i < ng) {
     double v = nu[i], wv = v > 0.0 ? v : 0.0;
@@ -1472,6 +1564,17 @@ __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, 
     if (threadIdx.x == 0) { atomicAdd(&acc[0], r2); atomicAdd(&acc[1], k2); atomicAdd(&acc[2], w2); }
   }
   if (i == 0 && kappa) *kappa = 1.0;
+}
+__global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, const double* __restrict__ p,
+                                                         const double* __restrict__ ww, const double* __restrict__ c,
+                                                         const double* __restrict__ x, const unsigned int* __restrict__ gidx,
+                                                         double* __restrict__ nu, const double* __restrict__ w,
+                                                         double alpha, double* __restrict__ kappa, double* __restrict__ acc,
+                                                         long long lo, long long hi, int acc_s) { update_nu_body(blockIdx.x, ng, nmat, p, ww, c, x, gidx, nu, w, alpha, kappa, acc, lo, hi, acc_s); }
+__global__ __launch_bounds__(kThreads) void k_update_nu_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  if ((long long)blockIdx.x * kThreads >= (long long)a.ng + a.nmat) return;
+  update_nu_body(blockIdx.x, a.ng, a.nmat, a.p, a.ww, a.c, a.x, a.gidx, a.nu, a.w, a.alpha, a.kappa, nullptr, 0LL, a.nmat, 1);
 }
 
 // check iteration, dual side: t[e] = (K'y)[e] = sum_g A[e,g] ys[g] + wgt * sum_src y_k[src],

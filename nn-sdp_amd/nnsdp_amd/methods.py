@@ -412,20 +412,31 @@ def comm_unique_id() -> bytes:
 
 
 class SolverBatch:
-    """Independent SDPs solved side by side on one GPU (one HIP stream each): the beta sweep of
-    experiments/scale.jl:28 or the hyperplane directions of NnSdp.findReach2Dpoly (src/NnSdp.jl:73-95).
-    A single W40-D20 SDP occupies 19 of the 256 CUs; a batch fills the chip with the same kernels.  Set
-    GPU_MAX_HW_QUEUES (e.g. 16) in the environment before HIP initialises: with the default 4 hardware queues
-    at most 4 streams make progress at a time."""
+    """Independent SDPs advanced in lockstep on one GPU: the beta sweep of experiments/scale.jl:28, the hyperplane
+    directions of NnSdp.findReach2Dpoly (src/NnSdp.jl:73-95), the sub-queries of an ACAS clause.  A single W40-D20
+    SDP occupies 19 of the 256 CUs; the batch handle (nnsdp_batch_*) issues ONE launch per stage for all SDPs.
+    `iterate_streams` is the older form, one HIP stream per SDP (set GPU_MAX_HW_QUEUES, e.g. 16, before HIP
+    initialises: with the default 4 hardware queues at most 4 streams make progress at a time)."""
 
-    def __init__(self, queries, opts: AdmmSdpOptions):
-        self.solvers = [Solver(q, opts) for q in queries]
+    def __init__(self, queries, opts):
+        optl = list(opts) if isinstance(opts, (list, tuple)) else [opts] * len(queries)
+        if len(optl) != len(queries):
+            raise ValueError("one options object per query (or a single one for all)")
+        self.solvers = [Solver(q, o) for q, o in zip(queries, optl)]
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        hs = (C.c_void_p * len(self.solvers))(*[s.h for s in self.solvers])
+        _lib.check(self.lib.nnsdp_batch_create(hs, len(self.solvers), C.byref(self.h)))
 
     def advance(self, iters: int) -> None:
         for s in self.solvers:
             s.advance(iters)
 
-    def iterate(self, iters: int, chunk: int = 64) -> None:
+    def iterate(self, iters: int) -> None:
+        """exactly `iters` plain iterations of every SDP, one launch per stage for the whole batch."""
+        _lib.check(self.lib.nnsdp_batch_iterate(self.h, int(iters)))
+
+    def iterate_streams(self, iters: int, chunk: int = 64) -> None:
         done = 0
         while done < iters:
             n = min(chunk, iters - done)
@@ -435,6 +446,17 @@ class SolverBatch:
         for s in self.solvers:
             s.sync()
 
+    def run(self) -> List[QuerySolution]:
+        """full solves (stopping rules of runQuery, each SDP on its own) -> one QuerySolution per query."""
+        st = (C.c_int32 * len(self.solvers))()
+        _lib.check(self.lib.nnsdp_batch_run(self.h, st))
+        out = []
+        for s, code in zip(self.solvers, st):
+            r, bufs = _alloc_result(s.cp)
+            _lib.check(self.lib.nnsdp_solver_finish_status(s.h, int(code), C.byref(r)))
+            out.append(_solution(s.cp, r, bufs))
+        return out
+
     def residuals(self):
         return [s.residuals() for s in self.solvers]
 
@@ -442,8 +464,26 @@ class SolverBatch:
         return [s.finish() for s in self.solvers]
 
     def close(self):
+        if self.h:
+            self.lib.nnsdp_batch_destroy(self.h)
+            self.h = C.c_void_p()
         for s in self.solvers:
             s.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def runQueries(queries, opts) -> List[QuerySolution]:
+    """runQuery for several independent queries at once (batch handle); results in the order of the queries."""
+    sb = SolverBatch(queries, opts)
+    try:
+        return sb.run()
+    finally:
+        sb.close()
 
 
 def makeZ(query, gamma) -> np.ndarray:

@@ -358,8 +358,8 @@ def test_acas_shaped_safety_query_tracks_oracle():
 
 
 def test_solver_batch_matches_single_solves():
-    """independent SDPs side by side on one GPU (SolverBatch, one HIP stream per handle) give exactly the
-    iterates of the same problems solved one after the other."""
+    """independent SDPs advanced in lockstep by the batch handle (one launch per stage for all of them, mixed sizes)
+    give exactly the iterates of the same problems solved one after the other; so does the one-stream-per-SDP form."""
     ds = [helpers.load_problem("W10-D5", 0), helpers.load_problem("W10-D5", 3), helpers.load_problem("W10-D10", 0)]
     qs = [helpers.product_query(d) for d in ds]
     opts = na.AdmmSdpOptions(max_iters=10 ** 8, proj_tol=1e-12)
@@ -367,12 +367,37 @@ def test_solver_batch_matches_single_solves():
     sb.iterate(300)
     rb = sb.residuals()
     sb.close()
-    for q, r in zip(qs, rb):
+    ss = na.SolverBatch(qs, opts)
+    ss.iterate_streams(300)
+    rs = ss.residuals()
+    ss.close()
+    for q, r, r2 in zip(qs, rb, rs):
         sv = na.Solver(q, opts)
         sv.iterate(300)
         r1 = sv.residuals()
         sv.close()
         assert np.allclose(r, r1, rtol=1e-9, atol=1e-14)
+        assert np.allclose(r2, r1, rtol=1e-9, atol=1e-14)
+
+
+def test_run_queries_batched_matches_run_query():
+    """full solves through the batch handle: per-SDP stopping (the three problems need different iteration counts, so
+    the batch shrinks twice), certificate polish and result packaging as in runQuery."""
+    ds = [helpers.load_problem("W10-D5", 0), helpers.load_problem("W10-D10", 2), helpers.load_problem("W10-D5", 3)]
+    qs = [helpers.product_query(d) for d in ds]
+    opts = na.AdmmSdpOptions(max_iters=200000, eps_rel=1e-6)
+    sols = na.runQueries(qs, opts)
+    its = []
+    for q, sb in zip(qs, sols):
+        s1 = na.runQuery(q, opts)
+        assert sb.termination_status == s1.termination_status == "OPTIMAL"
+        assert abs(sb.objective_value - s1.objective_value) <= 2e-6 * abs(s1.objective_value)
+        assert sb.summary["lambda_max"] <= 1e-6 and all(np.all(sb.values[k] >= 0) for k in ("γin", "γac1", "γac2", "γout"))
+        assert sb.summary["iters"] == s1.summary["iters"]      # same stopping rule on the same iterates
+        its.append(sb.summary["iters"])
+    assert len(set(its)) > 1
+    with pytest.raises(na._lib.NnsdpError):
+        na.SolverBatch([], opts)
 
 
 def test_clique_sharded_mode_single_rank_rccl():
