@@ -127,18 +127,16 @@ def findCircle(net, x1min, x1max, beta: int, opts: M.AdmmSdpOptions):
     return M.runQuery(q, opts)
 
 
-def findReach2Dpoly(net, x1min, x1max, beta: int, opts: M.AdmmSdpOptions, num_hplanes: int = 6):
+def findReach2Dpoly(net, x1min, x1max, beta: int, opts: M.AdmmSdpOptions, num_hplanes: int = 6, batched: bool = True):
+    """NnSdp.findReach2Dpoly (src/NnSdp.jl:73-95): one reach-hyperplane SDP per direction.  The directions share the
+    network and the interval pre-processing and are independent SDPs of identical shape: solved in lockstep through
+    the batch handle (`batched=False`: one after the other, as the reference does)."""
     qc_input = M.QcInputBox(x1min=x1min, x1max=x1max)
     qc_activs = makeQcActivs(net, x1min, x1max, beta)
-    hplanes, solns = [], []
-    for i in range(num_hplanes):
-        th = (i / num_hplanes) * 2 * np.pi
-        normal = np.array([np.cos(th), np.sin(th)])
-        q = M.ReachQuery(ffnet=net, qc_input=qc_input, qc_reach=M.QcReachHplane(normal=normal), qc_activs=qc_activs)
-        s = M.runQuery(q, opts)
-        hplanes.append((normal, s.objective_value))
-        solns.append(s)
-    return hplanes, solns
+    normals = [np.array([np.cos(2 * np.pi * i / num_hplanes), np.sin(2 * np.pi * i / num_hplanes)]) for i in range(num_hplanes)]
+    queries = [M.ReachQuery(ffnet=net, qc_input=qc_input, qc_reach=M.QcReachHplane(normal=nrm), qc_activs=qc_activs) for nrm in normals]
+    solns = M.runQueries(queries, opts) if batched and len(queries) > 1 else [M.runQuery(q, opts) for q in queries]
+    return [(nrm, s.objective_value) for nrm, s in zip(normals, solns)], solns
 
 
 def write_scale_csv(path: str, rows: Sequence[Tuple[int, M.QuerySolution]]):

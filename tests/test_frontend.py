@@ -119,3 +119,22 @@ def test_find_ellipsoid_end_to_end_gpu():
     Y = na.evalFeedFwdNet(net, 0.5 + rng.random((2, 20000)))
     invP = np.linalg.inv(P / np.sqrt(soln.objective_value))
     assert (np.sum((invP @ Y - yc[:, None]) ** 2, axis=0)).max() <= soln.objective_value * (1 + 1e-9)
+
+
+@pytest.mark.gpu
+def test_find_reach_2d_poly_batched_matches_sequential():
+    """the 6 hyperplane SDPs of findReach2Dpoly in lockstep through the batch handle against one-by-one solves; every
+    sampled output lies inside the certified polytope (src/NnSdp.jl:73-95)."""
+    d = helpers.load_problem("W10-D5", 0)
+    net = na.FeedFwdNet(xdims=[int(v) for v in d["xdims"]], Ms=helpers.problem_Ms(d))
+    opts = na.AdmmSdpOptions(max_iters=100000, eps_rel=1e-6)
+    hb, sb = na.findReach2Dpoly(net, d["x1min"], d["x1max"], 1, opts)
+    hs, ss = na.findReach2Dpoly(net, d["x1min"], d["x1max"], 1, opts, batched=False)
+    assert len(hb) == 6 and all(s.termination_status == "OPTIMAL" for s in sb + ss)
+    for (nb, ob), (n1, o1) in zip(hb, hs):
+        assert np.array_equal(nb, n1) and abs(ob - o1) <= 1e-5 * max(1.0, abs(o1))
+    rng = np.random.default_rng(0)
+    X = d["x1min"][:, None] + (d["x1max"] - d["x1min"])[:, None] * rng.random((2, 5000))
+    Y = na.evalFeedFwdNet(net, X)
+    for nrm, off in hb:
+        assert np.all(nrm @ Y <= off + 1e-6)
