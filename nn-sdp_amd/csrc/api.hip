@@ -988,7 +988,8 @@ struct nnsdp_batch {
       const int sc = act[0]->since_cold;   // equal for all active solvers
       const bool warm_ok = act[0]->opt.warm_start != 0 && sc < nnsdp_solver::kColdPeriod;
       int did;
-      if (warm_ok && left >= kGraphIters && nnsdp_solver::kColdPeriod - sc >= kGraphIters) {
+      static const bool no_graph = [] { const char* e = std::getenv("NNSDP_NO_GRAPH"); return e && std::atoi(e) != 0; }();   // diagnostic: eager launches only
+      if (!no_graph && warm_ok && left >= kGraphIters && nnsdp_solver::kColdPeriod - sc >= kGraphIters) {
         if (!gexec) {
           HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
           for (int i = 0; i < kGraphIters; ++i) enqueue_iteration(true);
