@@ -463,11 +463,11 @@ struct nnsdp_solver {
                          comm ? hsum.p : (const double*)nullptr);
     }
     hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
-    hipLaunchKernelGGL(k_spmv_A_x, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, D.csr_ptr.p, D.csr_col.p,
-                       D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p);
-    if (nlong > 0)
-      hipLaunchKernelGGL(k_spmv_A_x_long, dim3(nlong), dim3(kThreads), 0, st, nlong, d_long.p, D.csr_ptr.p, D.csr_col.p, D.csr_val.p,
-                         ww.p, g.p, D.Dinv.p, x.p);
+    {
+      const int nreg = cdiv((long long)NE * kRowLanes, kThreads);
+      hipLaunchKernelGGL(k_spmv_A_x_all, dim3(nreg + nlong), dim3(kThreads), 0, st, NE, nreg, nlong, d_long.p, D.csr_ptr.p, D.csr_col.p,
+                         D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p);
+    }
     if (check)
       hipLaunchKernelGGL(k_check_obj, dim3(cdiv(std::max(ng, NE), kThreads)), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p,
                          x.p, d_sigma(), acc.p);
@@ -956,7 +956,7 @@ struct nnsdp_batch {
       gx_gather = std::max(gx_gather, cdiv(a.NE, kThreads));
       gx_at = std::max(gx_at, cdiv((long long)a.ng * 64, kThreads));
       gx_gemv = gx_at;
-      gx_ax = std::max(gx_ax, cdiv((long long)a.NE * 16, kThreads));
+      gx_ax = std::max(gx_ax, cdiv((long long)a.NE * kRowLanes, kThreads));
       gx_long = std::max(gx_long, a.nlong);
       gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
     }
@@ -974,8 +974,7 @@ struct nnsdp_batch {
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
-    hipLaunchKernelGGL(k_spmv_A_x_b, dim3(gx_ax, B), dim3(kThreads), 0, st, d_it.p);
-    if (gx_long > 0) hipLaunchKernelGGL(k_spmv_A_x_long_b, dim3(gx_long, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_spmv_A_x_all_b, dim3(gx_ax + gx_long, B), dim3(kThreads), 0, st, d_it.p, gx_ax);
     hipLaunchKernelGGL(k_update_nu_b, dim3(gx_upd, B), dim3(kThreads), 0, st, d_it.p);
     HIPCHK(hipGetLastError());
   }

@@ -1480,20 +1480,22 @@ __global__ __launch_bounds__(kThreads) void k_gemv_sym_b(const IterArgs* __restr
   gemv_sym_body(blockIdx.x, a.ng, a.ldm, a.Minv, a.qv, a.ww);
 }
 
-// x[e] = g[e] - Dinv[e] * sum_g A[e,g] ww[g]; 16 lanes per pattern entry
+// x[e] = g[e] - Dinv[e] * sum_g A[e,g] ww[g]; 4 lanes per pattern entry (W40-D20: 27.6 k rows, 60 % of them with no
+// multiplier at all and 37 % with one; only 2 880 rows carry more than 16 nonzeros)
+static constexpr int kRowLanes = 4;
 static constexpr int kLongRow = 256;   // rows of A with more nonzeros go to the block-per-row kernel
 __device__ __forceinline__ void spmv_A_x_body(const int bid, int NE, const int* __restrict__ ptr, const int* __restrict__ col,
                                                         const double* __restrict__ val, const double* __restrict__ ww,
                                                         const double* __restrict__ g, const double* __restrict__ Dinv,
                                                         double* __restrict__ x) {
-  int e = (bid * kThreads + threadIdx.x) >> 4;
-  int sub = threadIdx.x & 15;
+  int e = (bid * kThreads + threadIdx.x) / kRowLanes;
+  int sub = threadIdx.x & (kRowLanes - 1);
   double s = 0.0;
   bool mine = e < NE && ptr[e + 1] - ptr[e] <= kLongRow;
   if (mine)
-    for (int q = ptr[e] + sub; q < ptr[e + 1]; q += 16) s += val[q] * ww[col[q]];
+    for (int q = ptr[e] + sub; q < ptr[e + 1]; q += kRowLanes) s += val[q] * ww[col[q]];
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
+  for (int o = kRowLanes / 2; o > 0; o >>= 1) s += __shfl_down(s, o, kRowLanes);
   if (mine && sub == 0) x[e] = g[e] - Dinv[e] * s;
 }
 __global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __restrict__ ptr, const int* __restrict__ col,
@@ -1502,7 +1504,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __rest
                                                         double* __restrict__ x) { spmv_A_x_body(blockIdx.x, NE, ptr, col, val, ww, g, Dinv, x); }
 __global__ __launch_bounds__(kThreads) void k_spmv_A_x_b(const IterArgs* __restrict__ A) {
   const IterArgs a = A[blockIdx.y];
-  if ((long long)blockIdx.x * kThreads >= (long long)a.NE * 16) return;
+  if ((long long)blockIdx.x * kThreads >= (long long)a.NE * kRowLanes) return;
   spmv_A_x_body(blockIdx.x, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
 }
 
@@ -1526,6 +1528,27 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x_long_b(const IterArgs* __
   const IterArgs a = A[blockIdx.y];
   if ((long long)blockIdx.x * kThreads >= (long long)a.nlong * kThreads) return;
   spmv_A_x_long_body(blockIdx.x, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+}
+
+// both forms in one launch: blocks [0, nreg) take the short rows 4 lanes each, blocks [nreg, nreg + nlong) one long row each
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_all(int NE, int nreg, int nlong, const int* __restrict__ rows,
+                                                            const int* __restrict__ ptr, const int* __restrict__ col,
+                                                            const double* __restrict__ val, const double* __restrict__ ww,
+                                                            const double* __restrict__ g, const double* __restrict__ Dinv,
+                                                            double* __restrict__ x) {
+  if ((int)blockIdx.x < nreg) spmv_A_x_body(blockIdx.x, NE, ptr, col, val, ww, g, Dinv, x);
+  else spmv_A_x_long_body(blockIdx.x - nreg, nlong, rows, ptr, col, val, ww, g, Dinv, x);
+}
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_all_b(const IterArgs* __restrict__ A, int nreg_max) {
+  const IterArgs a = A[blockIdx.y];
+  if ((int)blockIdx.x < nreg_max) {
+    if ((long long)blockIdx.x * kThreads >= (long long)a.NE * kRowLanes) return;
+    spmv_A_x_body(blockIdx.x, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+  } else {
+    const int b = blockIdx.x - nreg_max;
+    if (b >= a.nlong) return;
+    spmv_A_x_long_body(b, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+  }
 }
 
 // nu <- nu + alpha (K x + q - w).  acc (may be null) accumulates at check iterations:
