@@ -216,25 +216,35 @@ def isSolutionGood(soln: M.QuerySolution) -> bool:
 
 
 def verifyAcasSpec(net: M.FeedFwdNet, spec, beta: int, opts: M.AdmmSdpOptions,
-                   solve: Callable[[Any, M.AdmmSdpOptions], M.QuerySolution] = None, log: Callable[[str], None] = None):
+                   solve: Callable[[Any, M.AdmmSdpOptions], M.QuerySolution] = None, log: Callable[[str], None] = None,
+                   batch_clause: bool = False):
     """Goes through the conjunction; a clause holds as soon as one of its sub-queries is certified, the spec fails as
-    soon as a clause has none (experiments/acas.jl:87-137).  -> (solutions tried, number of queries, status)."""
+    soon as a clause has none (experiments/acas.jl:87-137).  -> (solutions tried, number of queries, status).
+    batch_clause: the sub-queries of a clause are independent SDPs on one network - solve them in lockstep through the
+    batch handle (runQueries) instead of one after the other; every literal of a tried clause then counts as run."""
     solve = solve or M.solveQuery
     cnf = loadReluQueriesCnf(net, spec, beta)
     num_queries = sum(len(c) for c in cnf)
     solns, status = [], "safe"
     for ci, clause in enumerate(cnf):
         holds = False
-        for qi, q in enumerate(clause):
-            s = solve(q, opts)
-            solns.append(s)
-            good = isSolutionGood(s)
+        if batch_clause and len(clause) > 1:
+            got = M.runQueries(clause, opts)
+            solns.extend(got)
+            holds = any(isSolutionGood(s) for s in got)
             if log:
-                log(f"conj {ci + 1}/{len(cnf)} subquery {qi + 1}/{len(clause)}: {s.termination_status} "
-                    f"time {s.total_time:.3f}s lambda_max {s.summary.get('lambda_max', float('nan')):.3e} good={good}")
-            if good:
-                holds = True
-                break
+                log(f"conj {ci + 1}/{len(cnf)}: {len(clause)} subqueries in one batch, certified: {[isSolutionGood(s) for s in got]}")
+        else:
+            for qi, q in enumerate(clause):
+                s = solve(q, opts)
+                solns.append(s)
+                good = isSolutionGood(s)
+                if log:
+                    log(f"conj {ci + 1}/{len(cnf)} subquery {qi + 1}/{len(clause)}: {s.termination_status} "
+                        f"time {s.total_time:.3f}s lambda_max {s.summary.get('lambda_max', float('nan')):.3e} good={good}")
+                if good:
+                    holds = True
+                    break
         if not holds:
             status = "unsafe"
             break
@@ -246,12 +256,12 @@ QUERY_COLUMNS = ["acas", "spec", "qnum", "num_queries", "time", "status", "eigma
 
 
 def verifyPairs(pairs: Sequence[Tuple[str, M.FeedFwdNet, str, Any]], beta: int, opts: M.AdmmSdpOptions, saveto: str = None,
-                solve=None, log=None):
+                solve=None, log=None, batch_clause: bool = False):
     """pairs: (network name, network, spec name, spec path or text).  Writes the reference's two tables
     (experiments/acas.jl:146-185): `saveto` and `saveto + "-qdf.csv"`, re-saved after every pair."""
     rows, qrows = [], []
     for name, net, sname, spec in pairs:
-        solns, nq, status = verifyAcasSpec(net, spec, beta, opts, solve=solve, log=log)
+        solns, nq, status = verifyAcasSpec(net, spec, beta, opts, solve=solve, log=log, batch_clause=batch_clause)
         good = [s for s in solns if isSolutionGood(s)]
         avg = sum(s.total_time for s in good) / len(good) if good else float("inf")
         rows.append([name, sname, status, nq, len(solns), avg, sum(s.total_time for s in solns)])

@@ -144,3 +144,21 @@ def test_verify_safe_and_unsafe_property_on_gpu(tmp_path):
     rows, qrows = vl.verifyPairs([("W10-D5", net, "prop_or_inputs", os.path.join(SPEC, "prop_or_inputs.vnnlib"))], 1, opts,
                                  saveto=str(tmp_path / "t.csv"))
     assert rows[0][2:5] == ["safe", 2, 2]
+
+
+@pytest.mark.gpu
+def test_clause_literals_in_one_batch_on_gpu():
+    """a clause with several literals (ACAS prop_7 style): sequential early exit and the batched form agree on the verdict;
+    the batched form runs every literal of the clauses it tries."""
+    d = helpers.load_problem("W10-D5", 0)
+    net = na.FeedFwdNet(xdims=[int(v) for v in d["xdims"]], Ms=helpers.problem_Ms(d))
+    spec = """
+    (assert (>= X_0 0.5)) (assert (<= X_0 1.5)) (assert (>= X_1 0.5)) (assert (<= X_1 1.5))
+    (assert (or (and (<= Y_0 10.0) (>= Y_1 20.0)) (and (>= Y_0 15.0) (>= Y_1 -50.0))))
+    """
+    opts = na.AdmmSdpOptions(max_iters=4000, eps_rel=1e-5)
+    s1, nq, st1 = vl.verifyAcasSpec(net, spec, 1, opts)
+    s2, nq2, st2 = vl.verifyAcasSpec(net, spec, 1, opts, batch_clause=True)
+    # clause 1: "Y_0 <= 10" cannot be refuted (it is true), "Y_1 >= 20" can; clause 2: "Y_0 >= 15" can
+    assert (nq, nq2, st1, st2) == (4, 4, "safe", "safe")
+    assert len(s1) == 3 and len(s2) == 4
