@@ -218,6 +218,7 @@ struct nnsdp_solver {
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
   DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc, gs;
+  DBuf<double> symv_part;   // batch handles: partial products of the tiled symmetric M^-1 q
   double sigma = 1.0, proj_tol = 1e-4;
   hipStream_t st = nullptr;
   hipGraph_t graph = nullptr;
@@ -895,7 +896,7 @@ struct nnsdp_batch {
   int nblocks = 0, nmax = 0, alg = 0;
   bool v_lds = true;
   size_t lds = 0;
-  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0;
+  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   static constexpr int kGraphIters = 8;
@@ -929,7 +930,7 @@ struct nnsdp_batch {
     std::vector<IterArgs> it;
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
-    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = 0;
+    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = 0;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
       HIPCHK(hipStreamSynchronize(s->st));
@@ -943,6 +944,13 @@ struct nnsdp_batch {
       a.z0 = s->D.z0.p; a.Dinv = s->D.Dinv.p; a.c = s->D.c.p; a.Minv = s->Minv.p;
       a.nu = s->nu.p; a.w = s->w.p; a.g = s->g.p; a.p = s->p.p; a.qv = s->qv.p; a.ww = s->ww.p; a.x = s->x.p;
       a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
+      {
+        const size_t nb = (size_t)(a.ng + 63) / 64;
+        if (s->symv_part.n != nb * nb * 64) s->symv_part.alloc(nb * nb * 64);
+        a.symv_part = s->symv_part.p;
+        gx_tiles = std::max(gx_tiles, cdiv((long long)(nb * (nb + 1) / 2), kThreads / 64));
+        gx_nb = std::max(gx_nb, (int)nb);
+      }
       it.push_back(a);
       ProjArgs q;
       q.cn = s->d_cn.p; q.coff = s->d_coff.p; q.eoff = nullptr;
@@ -973,7 +981,12 @@ struct nnsdp_batch {
     if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
-    hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
+    static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic
+    if (full_gemv) hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
+    else {
+      hipLaunchKernelGGL(k_symv_tiles_b, dim3(gx_tiles, B), dim3(kThreads), 0, st, d_it.p);
+      hipLaunchKernelGGL(k_symv_reduce_b, dim3(gx_nb, B), dim3(64), 0, st, d_it.p);
+    }
     hipLaunchKernelGGL(k_spmv_A_x_all_b, dim3(gx_ax + gx_long, B), dim3(kThreads), 0, st, d_it.p, gx_ax);
     hipLaunchKernelGGL(k_update_nu_b, dim3(gx_upd, B), dim3(kThreads), 0, st, d_it.p);
     HIPCHK(hipGetLastError());

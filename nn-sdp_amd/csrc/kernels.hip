@@ -1369,6 +1369,7 @@ struct IterArgs {
   double* nu; double* w; double* g; double* p; double* qv; double* ww; double* x;
   const double* sigma; double* kappa;
   double alpha;
+  double* symv_part;     // [nb][nb][64] partial products of the tiled symmetric M^-1 q (batch handles), nb = ceil(ng / 64)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1478,6 +1479,82 @@ __global__ __launch_bounds__(kThreads) void k_gemv_sym_b(const IterArgs* __restr
   const IterArgs a = A[blockIdx.y];
   if ((long long)blockIdx.x * kThreads >= (long long)a.ng * 64) return;
   gemv_sym_body(blockIdx.x, a.ng, a.ldm, a.Minv, a.qv, a.ww);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch handles: ww = Minv qv reading only the LOWER triangle of the symmetric Minv (half the HBM traffic of
+// k_gemv_sym; with 13 SDPs the product is 26 % of a lockstep iteration).  64 x 64 tiles (I >= J), one wave per tile:
+// lane r owns row r of the tile and adds T[r][c] x_J[c] over the columns (direct part, y_I); the transposed part
+// y_J[c] = sum_r T[r][c] x_I[r] needs a sum ACROSS lanes per column - done 8 columns at a time with a halving
+// exchange (4 + 2 + 1 values, then three full steps on one value: 10 exchanges per 8 columns instead of 48).
+// Every tile writes its two 64-vectors into its own slot of part[block][other block][64]; a second launch adds the
+// nb slots of every block in a fixed order, so the result does not depend on scheduling.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_symv_tiles_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  const int n = a.ng, nb = (n + 63) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (t >= nb * (nb + 1) / 2) return;
+  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int J = t - I * (I + 1) / 2;
+  const int r0 = I << 6, c0 = J << 6;
+  const int row = r0 + lane;
+  const bool rv = row < n;
+  const double* __restrict__ x = a.qv;
+  const double* __restrict__ Mp = a.Minv + row;
+  const double xi = rv ? x[row] : 0.0;
+  double acc = 0.0;        // direct part: row `row` of y_I
+  double outT = 0.0;       // transposed part: column tcol(lane) of y_J
+  const int ldm = a.ldm;
+#pragma unroll 1
+  for (int g8 = 0; g8 < 8; ++g8) {
+    double p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + 8 * g8 + i;
+      const double v = (rv && c < n) ? Mp[(size_t)c * ldm] : 0.0;
+      const double xc = c < n ? x[c] : 0.0;      // wave-uniform
+      acc += v * xc;
+      p[i] = v * xi;
+    }
+    if (I != J) {
+      // 8 column sums over 64 lanes.  Halving steps over lane bits 5, 4, 3 ...
+      const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+      double q[4], r[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double send = h5 ? p[i] : p[4 + i], keep = h5 ? p[4 + i] : p[i]; q[i] = keep + __shfl_xor(send, 32, 64); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const double send = h4 ? q[i] : q[2 + i], keep = h4 ? q[2 + i] : q[i]; r[i] = keep + __shfl_xor(send, 16, 64); }
+      double sv;
+      { const double send = h3 ? r[0] : r[1], keep = h3 ? r[1] : r[0]; sv = keep + __shfl_xor(send, 8, 64); }
+      // ... then plain butterfly steps over bits 2, 1, 0
+      sv += __shfl_xor(sv, 4, 64);
+      sv += __shfl_xor(sv, 2, 64);
+      sv += __shfl_xor(sv, 1, 64);
+      // lane holds the sum of column 8 g8 + 4 h5 + 2 h4 + h3 of the tile; lanes with (lane & 7) == g8 keep it
+      if ((lane & 7) == g8) outT = sv;
+    }
+  }
+  double* part = a.symv_part;
+  part[((size_t)I * nb + J) * 64 + lane] = acc;
+  if (I != J) {
+    const int tc = 8 * (lane & 7) + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    part[((size_t)J * nb + I) * 64 + tc] = outT;
+  }
+}
+__global__ __launch_bounds__(64) void k_symv_reduce_b(const IterArgs* __restrict__ A) {
+  const IterArgs a = A[blockIdx.y];
+  const int n = a.ng, nb = (n + 63) >> 6;
+  const int b = blockIdx.x;
+  if (b >= nb) return;
+  const double* part = a.symv_part + (size_t)b * nb * 64 + threadIdx.x;
+  double s = 0.0;
+  for (int k = 0; k < nb; ++k) s += part[(size_t)k * 64];
+  const int row = b * 64 + threadIdx.x;
+  if (row < n) a.ww[row] = s;
 }
 
 // x[e] = g[e] - Dinv[e] * sum_g A[e,g] ww[g]; 4 lanes per pattern entry (W40-D20: 27.6 k rows, 60 % of them with no
