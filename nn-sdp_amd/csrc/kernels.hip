@@ -1552,7 +1552,15 @@ __global__ __launch_bounds__(64) void k_symv_reduce_b(const IterArgs* __restrict
   if (b >= nb) return;
   const double* part = a.symv_part + (size_t)b * nb * 64 + threadIdx.x;
   double s = 0.0;
-  for (int k = 0; k < nb; ++k) s += part[(size_t)k * 64];
+  int k = 0;
+  for (; k + 8 <= nb; k += 8) {          // loads of 8 slots in flight, added in slot order
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = part[(size_t)(k + i) * 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  for (; k < nb; ++k) s += part[(size_t)k * 64];
   const int row = b * 64 + threadIdx.x;
   if (row < n) a.ww[row] = s;
 }
