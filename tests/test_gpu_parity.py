@@ -62,6 +62,30 @@ def test_projection_edge_cases():
     assert np.abs(P[0] - _ref_proj(0.5 * (B + B.T))).max() <= 1e-10
 
 
+@pytest.mark.parametrize("alg", [0, 2, 3])
+@pytest.mark.parametrize("n", [49, 61, 90, 91, 96])
+def test_projection_variants_edge_cases(alg, n, monkeypatch):
+    """every sweep variant of the projection kernel (round robin in LDS, register-resident systolic, ping-pong odd-even
+    with scaled rotations; NNSDP_PROJ_ALG) on the hard inputs: zero / identity / definite / rank-1 / repeated and
+    clustered eigenvalues, odd sizes (a padded index travels through the positions), 1e-150 and 1e120 scales."""
+    monkeypatch.setenv("NNSDP_PROJ_ALG", str(alg))
+    rng = np.random.default_rng(100 * alg + n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    k = n // 3
+    cases = [np.zeros((n, n)), np.eye(n), -np.eye(n), (Q * np.linspace(0.1, 3, n)) @ Q.T, -(Q * np.linspace(0.1, 3, n)) @ Q.T,
+             np.outer(Q[:, 0], Q[:, 0]) * 2.5, (Q * np.repeat([2.0, -1.0, 0.0], [k, k, n - 2 * k])) @ Q.T,
+             (Q * np.concatenate([1.0 + 1e-9 * np.arange(k), -1.0 - 1e-7 * np.arange(k), 1e-8 * (np.arange(n - 2 * k) - 3.0)])) @ Q.T,
+             np.diag(np.arange(n) - n / 2.0), _sym(rng, n, 1e-150), _sym(rng, n, 1e120), _sym(rng, n)]
+    cases = [0.5 * (A + A.T) for A in cases]
+    res, evs, _ = na.project_psd_batched(cases)
+    for A, P, ev in zip(cases, res, evs):
+        nrm = max(np.abs(A).max(), 1e-300)
+        assert np.all(np.isfinite(P))
+        assert np.abs(P - _ref_proj(A)).max() <= 1e-10 * nrm
+        assert np.abs(np.sort(ev) - np.linalg.eigvalsh(A)).max() <= 1e-10 * nrm
+    assert np.array_equal(res[0], np.zeros((n, n)))
+
+
 def test_projection_properties_at_full_size():
     """size-independent properties on a batch that fills the chip: 256 blocks of n = 121 (the nominal
     W40 clique) and n = 85 (the largest block the normalised W40-D20 solve sees)."""
