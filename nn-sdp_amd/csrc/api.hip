@@ -917,6 +917,7 @@ struct nnsdp_batch {
       for (int j = 0; j < i; ++j) if (sv[j] == sv[i]) throw std::invalid_argument("a solver appears twice in the batch");
       all.push_back(sv[i]);
     }
+    if (sv[0]->opt.device >= 0) HIPCHK(hipSetDevice(sv[0]->opt.device));
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     status.assign(count, -1);
     act = all;
