@@ -8,7 +8,7 @@ from .methods import (  # noqa: F401
 )
 from .frontend import (  # noqa: F401
     read_nnet, evalFeedFwdNet, makeIntervalsInfo, makeQcActivs, approxEllipsoid,
-    findEllipsoid, findCircle, findReach2Dpoly, write_scale_csv,
+    findEllipsoid, findCircle, findReach2Dpoly, write_scale_csv, runScale, ellipsoidQuery,
 )
 from . import _lib  # noqa: F401
 from . import vnnlib  # noqa: F401

@@ -5,6 +5,7 @@
   makeQcActivs              QcActivBounded + QcActivSector src/Qc/activ.jl:45-72, makeSectorMinMax activ_sector.jl:63-90
   approxEllipsoid           sampled output ellipsoid      src/Utils/qc.jl:40-67
   findEllipsoid / findCircle / findReach2Dpoly            src/NnSdp.jl:35-95
+  runScale                  beta sweep of one network      experiments/scale.jl:52-82 (batch handle)
   write_scale_csv           dump/scale column layout      experiments/scale.jl:60-82
 
 These run once per query on the host; the interval pre-processing is native C++ inside libnnsdp_hip.so
@@ -110,11 +111,7 @@ def approxEllipsoid(net: M.FeedFwdNet, x1min, x1max, N: int = 100000, seed: int 
 
 
 def findEllipsoid(net, x1min, x1max, beta: int, opts: M.AdmmSdpOptions, seed: int = 1234):
-    qc_input = M.QcInputBox(x1min=x1min, x1max=x1max)
-    qc_activs = makeQcActivs(net, x1min, x1max, beta)
-    P, yc = approxEllipsoid(net, x1min, x1max, seed=seed)
-    invP = np.linalg.inv(P)
-    q = M.ReachQuery(ffnet=net, qc_input=qc_input, qc_reach=M.QcReachEllipsoid(invP=0.5 * (invP + invP.T), yc=yc), qc_activs=qc_activs)
+    q, P, yc = ellipsoidQuery(net, x1min, x1max, beta, seed=seed)
     soln = M.runQuery(q, opts)
     rho = max(float(soln.values["γout"][0]), 0.0)
     return np.sqrt(rho) * P, yc, soln
@@ -137,6 +134,29 @@ def findReach2Dpoly(net, x1min, x1max, beta: int, opts: M.AdmmSdpOptions, num_hp
     queries = [M.ReachQuery(ffnet=net, qc_input=qc_input, qc_reach=M.QcReachHplane(normal=nrm), qc_activs=qc_activs) for nrm in normals]
     solns = M.runQueries(queries, opts) if batched and len(queries) > 1 else [M.runQuery(q, opts) for q in queries]
     return [(nrm, s.objective_value) for nrm, s in zip(normals, solns)], solns
+
+
+def ellipsoidQuery(net, x1min, x1max, beta: int, seed: int = 1234):
+    """the ReachQuery NnSdp.findEllipsoid solves (src/NnSdp.jl:35-50) and the sampled shape matrix P."""
+    qc_input = M.QcInputBox(x1min=x1min, x1max=x1max)
+    qc_activs = makeQcActivs(net, x1min, x1max, beta)
+    P, yc = approxEllipsoid(net, x1min, x1max, seed=seed)
+    invP = np.linalg.inv(P)
+    q = M.ReachQuery(ffnet=net, qc_input=qc_input, qc_reach=M.QcReachEllipsoid(invP=0.5 * (invP + invP.T), yc=yc), qc_activs=qc_activs)
+    return q, P, yc
+
+
+def runScale(net, x1min, x1max, betas: Sequence[int], opts: M.AdmmSdpOptions, saveto: str = None, batched: bool = True, seed: int = 1234):
+    """The reference's headline experiment (experiments/scale.jl:52-82): findEllipsoid for every beta of a sweep on one
+    network, one CSV row per beta.  The SDPs of a sweep are independent and of different sizes (the sector QC grows with
+    beta): `batched` advances them in lockstep through the batch handle, each stopping on its own rule.
+    -> list of (beta, QuerySolution)."""
+    queries = [ellipsoidQuery(net, x1min, x1max, int(b), seed=seed)[0] for b in betas]
+    solns = M.runQueries(queries, opts) if batched and len(queries) > 1 else [M.runQuery(q, opts) for q in queries]
+    rows = list(zip([int(b) for b in betas], solns))
+    if saveto:
+        write_scale_csv(saveto, rows)
+    return rows
 
 
 def write_scale_csv(path: str, rows: Sequence[Tuple[int, M.QuerySolution]]):

@@ -1,6 +1,7 @@
 """Rows f1-f3 of SURVEY.md section 8: the product's host-side .nnet reader, CROWN-sliced intervals and QC
 construction against the oracle restatement and the committed fixtures (CPU), and the findEllipsoid
 front-end end to end on the GPU."""
+import csv
 import os
 
 import numpy as np
@@ -138,3 +139,24 @@ def test_find_reach_2d_poly_batched_matches_sequential():
     Y = na.evalFeedFwdNet(net, X)
     for nrm, off in hb:
         assert np.all(nrm @ Y <= off + 1e-6)
+
+
+@pytest.mark.gpu
+def test_run_scale_beta_sweep_batched(tmp_path):
+    """experiments/scale.jl on one network: the beta sweep (SDPs of different sizes) in lockstep through the batch handle
+    gives the rows of one-by-one solves; the published rows of dump/scale for this network are met within 1e-3."""
+    d = np.load(os.path.join(helpers.GOLDEN, "nets", "scale-I2-O2-W10-D10.npz"))
+    xd = [int(v) for v in d["xdims"]]
+    net = na.FeedFwdNet(xdims=xd, Ms=[np.array(d[f"M{k}"]) for k in range(len(xd) - 1)])
+    opts = na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), max_iters=400000, eps_rel=1e-6)
+    betas = [0, 3, 7]
+    out = str(tmp_path / "scale.csv")
+    rows = na.runScale(net, [0.5, 0.5], [1.5, 1.5], betas, opts, saveto=out)
+    seq = na.runScale(net, [0.5, 0.5], [1.5, 1.5], betas, opts, batched=False)
+    for (b, s), (b1, s1) in zip(rows, seq):
+        assert b == b1 and s.termination_status == s1.termination_status == "OPTIMAL"
+        assert abs(s.objective_value - s1.objective_value) <= 2e-6 * abs(s1.objective_value)
+        pub = helpers.published_rho("W10-D10", b)
+        assert pub and min(abs(s.objective_value - p) / abs(p) for p in pub) <= 1e-3
+    got = list(csv.reader(open(out)))
+    assert got[0] == ["beta", "setup_secs", "solve_secs", "total_secs", "obj_val", "term_status", "eigmax"] and [r[0] for r in got[1:]] == ["0", "3", "7"]
