@@ -95,3 +95,25 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   return QuerySolution(model = nothing, objective_value = res.objective, values = values, summary = res,
                        termination_status = status, total_time = res.t_total, setup_time = res.t_setup, solve_time = res.t_solve)
 end
+
+# Interval pre-processing without the PyCall / ONNX / auto_LiRPA bridge (replaces Intervals.intervalsAutoLirpaSliced,
+# src/Intervals/intervals_auto_lirpa.jl:12-64, and the sector test of Qc.makeSectorMinMax, src/Qc/activ_sector.jl:63-72).
+# Drop-in for Utils.makeQcActivs (src/Utils/qc.jl:6-24): same return value.
+function makeQcActivsNative(ffnet::FeedFwdNet; x1min::VecReal, x1max::VecReal, β::Int)
+  xdims = Int32.(ffnet.xdims)
+  M = vcat([vec(Matrix{Float64}(Mk)) for Mk in ffnet.Ms]...)       # column-major [W_k b_k], back to back
+  acdim = sum(ffnet.xdims[2:end-1])
+  acymin = zeros(acdim); acymax = zeros(acdim); smin = zeros(acdim); smax = zeros(acdim)
+  lo = Vector{Float64}(x1min); hi = Vector{Float64}(x1max)
+  GC.@preserve xdims M lo hi acymin acymax smin smax begin
+    rc = ccall((:nnsdp_make_intervals, LIBNNSDP), Cint,
+               (Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+               Int32(ffnet.K), pointer(xdims), pointer(M), pointer(lo), pointer(hi), pointer(acymin), pointer(acymax),
+               C_NULL, C_NULL, pointer(smin), pointer(smax), C_NULL, C_NULL)
+    rc == 0 || error("nnsdp_make_intervals failed ($rc): " * unsafe_string(ccall((:nnsdp_last_error, LIBNNSDP), Cstring, ())))
+  end
+  qc_bounded = QcActivBounded(acydim=acdim, acymin=acymin, acymax=acymax)
+  qc_sector = QcActivSector(activ=ffnet.activ, acxdim=acdim, β=β, base_smin=0.0, base_smax=1.0, smin=smin, smax=smax)
+  return [qc_bounded, qc_sector]
+end
