@@ -52,5 +52,10 @@ if k:
     print("k_proj_jacobi per launch: FETCH_SIZE KB", f, "WRITE_SIZE KB", w, "LDS conflict share",
           k.get("SQ_LDS_BANK_CONFLICT", {}).get("mean_per_launch", 0) / max(k.get("SQ_LDS_IDX_ACTIVE", {}).get("mean_per_launch", 1), 1))
 PY
-rm -rf $OUT/stats $OUT/pmc_*   # raw traces are large; only the aggregates travel back
+# batched regime (batch handle, 13 SDPs in lockstep); eager launches: rocprofv3 crashes on graph capture with many handles
+cd /tmp
+NNSDP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bstats -- python3 $R/tools/batch_bench.py 13 W40-D20 400 > $OUT/${TAG}_batched13_W40-D20.log 2> $OUT/bstats.err || true
+cd $R
+for f in $OUT/bstats/*/*kernel_stats.csv; do cp $f $OUT/${TAG}_batched13_W40-D20_kernel_stats.csv; done
+rm -rf $OUT/stats $OUT/pmc_* $OUT/bstats   # raw traces are large; only the aggregates travel back
 head -4 $OUT/${TAG}_bench_W40-D20_kernel_stats.csv | cut -c1-160
