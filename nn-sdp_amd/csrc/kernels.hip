@@ -1279,9 +1279,9 @@ inline bool proj_sys_ok(int nmax) { return nmax >= kSysMin && nmax <= 128; }
 inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   // V in LDS, 1024 threads
 #define NNSDP_PROJ_VARIANTS(X) \
   X((k_proj_jacobi<true, 1024, 1>)) X((k_proj_jacobi<true, 256, 1>)) X((k_proj_jacobi<true, 1024>)) X((k_proj_jacobi<false, 1024>)) \
-  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>)) \
+  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<false, 512, 2, 7, 14>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>)) \
   X((k_proj_jacobi_b<true, 1024>)) X((k_proj_jacobi_b<false, 1024>)) X((k_proj_jacobi_b<true, 256>)) X((k_proj_jacobi_b<false, 256>)) \
-  X((k_proj_jacobi_b<true, 512, 2, 6, 12>)) X((k_proj_jacobi_b<false, 512, 2, 8, 16>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 6>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 7>))
+  X((k_proj_jacobi_b<true, 512, 2, 6, 12>)) X((k_proj_jacobi_b<false, 512, 2, 8, 16>)) X((k_proj_jacobi_b<false, 512, 2, 7, 14>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 6>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 7>))
 inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
     if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
@@ -1290,6 +1290,7 @@ inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, si
   }
   if (alg == kProjSystolic && proj_sys_ok(nmax)) {
     if (v_lds) hipLaunchKernelGGL((k_proj_jacobi<true, 512, 2, 6, 12>), dim3(nblocks), dim3(512), lds, st, a);
+    else if (nmax <= 110) hipLaunchKernelGGL((k_proj_jacobi<false, 512, 2, 7, 14>), dim3(nblocks), dim3(512), lds, st, a);   // width-50 path cliques (101..103)
     else hipLaunchKernelGGL((k_proj_jacobi<false, 512, 2, 8, 16>), dim3(nblocks), dim3(512), lds, st, a);
     return;
   }
@@ -1316,6 +1317,7 @@ inline void launch_proj_batched(const ProjArgs* dargs, const int2* dmap, int nbl
   }
   if (alg == kProjSystolic && proj_sys_ok(nmax)) {
     if (v_lds) hipLaunchKernelGGL((k_proj_jacobi_b<true, 512, 2, 6, 12>), dim3(nblocks), dim3(512), lds, st, dargs, dmap);
+    else if (nmax <= 110) hipLaunchKernelGGL((k_proj_jacobi_b<false, 512, 2, 7, 14>), dim3(nblocks), dim3(512), lds, st, dargs, dmap);
     else hipLaunchKernelGGL((k_proj_jacobi_b<false, 512, 2, 8, 16>), dim3(nblocks), dim3(512), lds, st, dargs, dmap);
     return;
   }
