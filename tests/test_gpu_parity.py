@@ -86,6 +86,17 @@ def test_projection_variants_edge_cases(alg, n, monkeypatch):
     assert np.array_equal(res[0], np.zeros((n, n)))
 
 
+def test_projection_width50_path_cliques():
+    """blocks of 97..110 (the 2W+1 = 101 path cliques of width-50 nets) take the 7-slot systolic instantiation."""
+    rng = np.random.default_rng(11)
+    mats = [_sym(rng, n) for n in (97, 101, 103, 110)]
+    res, evs, _ = na.project_psd_batched(mats)
+    for A, P, ev in zip(mats, res, evs):
+        nrm = np.abs(A).max()
+        assert np.abs(P - _ref_proj(A)).max() <= 1e-10 * nrm
+        assert np.abs(np.sort(ev) - np.linalg.eigvalsh(A)).max() <= 1e-10 * nrm
+
+
 def test_projection_properties_at_full_size():
     """size-independent properties on a batch that fills the chip: 256 blocks of n = 121 (the nominal
     W40 clique) and n = 85 (the largest block the normalised W40-D20 solve sees)."""
