@@ -9,7 +9,8 @@ Fixtures are DATA only:
                              network, CROWN-sliced intervals, sector bounds, sampled ellipsoid
   golden_<name>_b<beta>.npz  oracle outputs on those inputs: clique lists, Z(gamma) probes,
                              adjoint probes
-Usage: python tools/make_fixtures.py [--ref /root/reference]
+Usage: python tests/golden/make_fixtures.py [--ref /root/reference]
+(test infrastructure: the only users of oracle/ are tests/, smoke() and bench.py's cpu_baseline leg)
 """
 import argparse
 import csv
@@ -19,7 +20,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import nnet_io, qc, operator as op  # noqa: E402
