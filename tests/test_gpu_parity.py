@@ -435,6 +435,27 @@ def test_run_queries_batched_matches_run_query():
         na.SolverBatch([], opts)
 
 
+def test_batch_handle_limits_and_errors():
+    """per-SDP options in a batch: one SDP runs into its iteration limit while the other converges; argument errors."""
+    q0 = helpers.product_query(helpers.load_problem("W10-D5", 0))
+    q1 = helpers.product_query(helpers.load_problem("W10-D5", 3))
+    sols = na.runQueries([q0, q1], [na.AdmmSdpOptions(max_iters=200), na.AdmmSdpOptions(max_iters=200000, eps_rel=1e-6)])
+    assert sols[0].termination_status == "ITERATION_LIMIT" and sols[0].summary["iters"] == 200
+    assert sols[1].termination_status == "OPTIMAL" and sols[1].summary["iters"] > 200
+    ref = na.runQuery(q1, na.AdmmSdpOptions(max_iters=200000, eps_rel=1e-6))
+    assert abs(sols[1].objective_value - ref.objective_value) <= 2e-6 * abs(ref.objective_value)
+    with pytest.raises(ValueError):
+        na.SolverBatch([q0, q1], [na.AdmmSdpOptions()])
+    with pytest.raises(na._lib.NnsdpError) as ei:
+        na.SolverBatch([q0, q1], [na.AdmmSdpOptions(check_every=50), na.AdmmSdpOptions(check_every=25)])
+    assert "check_every" in str(ei.value)
+    sb = na.SolverBatch([q0], na.AdmmSdpOptions())
+    with pytest.raises(na._lib.NnsdpError):
+        sb.iterate(-1)
+    sb.iterate(0)
+    sb.close()
+
+
 def test_clique_sharded_mode_single_rank_rccl():
     """the clique-sharded code path (own-clique projection, RCCL all-reduce of the consensus sum, replicated
     operator kernels) with a one-rank communicator must reproduce the unsharded iteration.  Multi-rank logic is
