@@ -626,8 +626,10 @@ struct nnsdp_solver {
     }
     // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
     if (opt.adapt_every > 0 && iters_done >= next_adapt) {
-      next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, iters_done * 3 / 2);
-      double ratio = std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
+      static const double geom = [] { const char* e = std::getenv("NNSDP_SIGMA_GEOM"); return e ? std::atof(e) : 1.5; }();   // diagnostic
+      static const double powr = [] { const char* e = std::getenv("NNSDP_SIGMA_POW"); return e ? std::atof(e) : 1.0; }();    // diagnostic
+      next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, (long long)(iters_done * geom));
+      double ratio = std::pow(std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300)), powr);
       if (ratio > 1.5 || ratio < 0.67) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
     }
     return -1;
