@@ -98,7 +98,7 @@ end
 
 # Interval pre-processing without the PyCall / ONNX / auto_LiRPA bridge (replaces Intervals.intervalsAutoLirpaSliced,
 # src/Intervals/intervals_auto_lirpa.jl:12-64, and the sector test of Qc.makeSectorMinMax, src/Qc/activ_sector.jl:63-72).
-# Drop-in for Utils.makeQcActivs (src/Utils/qc.jl:6-24): same return value.
+# Drop-in for Qc.makeQcActivs (src/Qc/activ.jl:45-72): same return value.
 function makeQcActivsNative(ffnet::FeedFwdNet; x1min::VecReal, x1max::VecReal, β::Int)
   xdims = Int32.(ffnet.xdims)
   M = vcat([vec(Matrix{Float64}(Mk)) for Mk in ffnet.Ms]...)       # column-major [W_k b_k], back to back

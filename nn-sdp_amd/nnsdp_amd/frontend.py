@@ -87,7 +87,7 @@ def makeIntervalsInfo(x1min, x1max, net: M.FeedFwdNet):
 
 
 def makeQcActivs(net: M.FeedFwdNet, x1min, x1max, beta: int):
-    """Utils.makeQcActivs (src/Utils/qc.jl:6-24): bounded + sector QCs from the interval pre-processing."""
+    """Qc.makeQcActivs (src/Qc/activ.jl:45-72): bounded + sector QCs from the interval pre-processing."""
     acymin, acymax, _, _, smin, smax, _, _ = _intervals_native(x1min, x1max, net)
     return [M.QcActivBounded(acymin=acymin, acymax=acymax),
             M.QcActivSector(acxdim=len(acymin), beta=int(beta), smin=smin, smax=smax)]
