@@ -13,7 +13,7 @@ from .frontend import (  # noqa: F401
 from . import _lib  # noqa: F401
 from . import vnnlib  # noqa: F401
 from .vnnlib import (  # noqa: F401
-    read_vnnlib, hplaneS, loadVnnlibCnf, loadReluQueriesCnf, verifyAcasSpec, verifyPairs, isSolutionGood, shardPairs,
+    read_vnnlib, hplaneS, loadVnnlibCnf, loadReluQueriesCnf, verifyAcasSpec, verifyPairs, isSolutionGood, shardPairs, reachForm, safetyFromReach,
 )
 
 __version__ = "0.1.0"

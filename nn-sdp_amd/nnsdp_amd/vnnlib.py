@@ -215,28 +215,82 @@ def isSolutionGood(soln: M.QuerySolution) -> bool:
     return bool(np.isfinite(lam) and lam <= NSD_TOL)
 
 
+def reachForm(query: M.SafetyQuery, ybounds=None):
+    """hyperplane safety literal  normal' y <= h  ->  (ReachQuery, h, h0): the reach query bounds normal' y - h0 on a copy
+    of the network whose output bias is shifted along the normal (the LMI is the same quadratic form).  By the
+    S-procedure the safety LMI is feasible iff the optimal offset rho' satisfies rho' + h0 <= h; the reach form has
+    cost-free multipliers, so the first-order solver eliminates fixed neurons, stops on a certified gap and returns
+    the margin.  h0 is a lower bound of normal' y over the box (interval arithmetic on the output bounds), so that the
+    optimum is nonnegative - the offset multiplier of a reach query is constrained to gamma_out >= 0."""
+    net = query.ffnet
+    d1, dK = net.xdims[0], net.xdims[-1]
+    S = np.asarray(query.qc_safety.S)
+    if np.any(S[:d1 + dK, :d1 + dK] != 0) or np.any(S[:d1, -1] != 0):
+        raise ValueError("reach form needs a hyperplane safety set (S = hplaneS(normal, h))")
+    normal, h = S[d1:d1 + dK, -1].copy(), -0.5 * float(S[-1, -1])
+    nn_ = float(normal @ normal)
+    if nn_ == 0.0:
+        raise ValueError("reach form needs a nonzero normal")
+    if ybounds is None:
+        xi, _ = F.makeIntervalsInfo(query.qc_input.x1min, query.qc_input.x1max, net)
+        ybounds = xi[-1]
+    ylo, yhi = ybounds
+    h0 = float(np.maximum(normal, 0) @ ylo + np.minimum(normal, 0) @ yhi)
+    h0 -= 1e-6 * max(1.0, abs(h0))
+    Ms = [np.array(Mk, dtype=np.float64, copy=True) for Mk in net.Ms]
+    Ms[-1][:, -1] -= (h0 / nn_) * normal
+    shifted = M.FeedFwdNet(xdims=list(net.xdims), Ms=Ms)
+    rq = M.ReachQuery(ffnet=shifted, qc_input=query.qc_input, qc_reach=M.QcReachHplane(normal=normal), qc_activs=query.qc_activs)
+    return rq, h, h0
+
+
+def safetyFromReach(soln: M.QuerySolution, h: float, h0: float = 0.0) -> M.QuerySolution:
+    """the safety certificate a reach-hyperplane solution implies: same multipliers, Z_safety = Z_reach - 2 (h - rho) e_a e_a'
+    with rho = objective + h0 (NSD whenever Z_reach is and rho <= h).  The literal is certified iff gamma >= 0 and
+    eigmax(Z_safety) <= NSD_TOL (termination_status "OPTIMAL", else "INFEASIBLE"); margin = h - rho."""
+    rho = float(soln.objective_value) + h0
+    Z = np.array(soln.values["Z"], dtype=np.float64, copy=True)
+    Z[-1, -1] -= 2.0 * (h - rho)
+    lam = float(np.linalg.eigvalsh(0.5 * (Z + Z.T))[-1])
+    ok = bool(np.isfinite(lam) and lam <= NSD_TOL)
+    vals = {k: v for k, v in soln.values.items() if k != "γout"}
+    vals["Z"] = Z
+    summ = dict(soln.summary)
+    summ.update(lambda_max=lam, reach_bound=rho, offset=h, margin=h - rho, reach_status=soln.termination_status)
+    obj = float(sum(np.sum(vals[k]) for k in ("γin", "γac1", "γac2")))
+    return M.QuerySolution(objective_value=obj, values=vals, termination_status="OPTIMAL" if ok else "INFEASIBLE",
+                           total_time=soln.total_time, setup_time=soln.setup_time, solve_time=soln.solve_time, summary=summ)
+
+
 def verifyAcasSpec(net: M.FeedFwdNet, spec, beta: int, opts: M.AdmmSdpOptions,
                    solve: Callable[[Any, M.AdmmSdpOptions], M.QuerySolution] = None, log: Callable[[str], None] = None,
-                   batch_clause: bool = False):
+                   batch_clause: bool = False, via_reach: bool = False):
     """Goes through the conjunction; a clause holds as soon as one of its sub-queries is certified, the spec fails as
     soon as a clause has none (experiments/acas.jl:87-137).  -> (solutions tried, number of queries, status).
     batch_clause: the sub-queries of a clause are independent SDPs on one network - solve them in lockstep through the
-    batch handle (runQueries) instead of one after the other; every literal of a tried clause then counts as run."""
+    batch handle (runQueries) instead of one after the other; every literal of a tried clause then counts as run.
+    via_reach: decide every literal through the equivalent reach-hyperplane query (reachForm / safetyFromReach) - the
+    feasibility form 'min sum(gamma)' of the reference needs an interior-point solver to FAIL quickly; the reach form
+    ends in bounded time either way and reports the margin."""
     solve = solve or M.solveQuery
     cnf = loadReluQueriesCnf(net, spec, beta)
     num_queries = sum(len(c) for c in cnf)
     solns, status = [], "safe"
     for ci, clause in enumerate(cnf):
         holds = False
+        forms = [reachForm(q) for q in clause] if via_reach else [(q, None, None) for q in clause]
         if batch_clause and len(clause) > 1:
-            got = M.runQueries(clause, opts)
+            got = M.runQueries([f[0] for f in forms], opts)
+            got = [safetyFromReach(s, f[1], f[2]) if via_reach else s for s, f in zip(got, forms)]
             solns.extend(got)
             holds = any(isSolutionGood(s) for s in got)
             if log:
                 log(f"conj {ci + 1}/{len(cnf)}: {len(clause)} subqueries in one batch, certified: {[isSolutionGood(s) for s in got]}")
         else:
-            for qi, q in enumerate(clause):
+            for qi, (q, h, h0) in enumerate(forms):
                 s = solve(q, opts)
+                if via_reach:
+                    s = safetyFromReach(s, h, h0)
                 solns.append(s)
                 good = isSolutionGood(s)
                 if log:
@@ -256,12 +310,12 @@ QUERY_COLUMNS = ["acas", "spec", "qnum", "num_queries", "time", "status", "eigma
 
 
 def verifyPairs(pairs: Sequence[Tuple[str, M.FeedFwdNet, str, Any]], beta: int, opts: M.AdmmSdpOptions, saveto: str = None,
-                solve=None, log=None, batch_clause: bool = False):
+                solve=None, log=None, batch_clause: bool = False, via_reach: bool = False):
     """pairs: (network name, network, spec name, spec path or text).  Writes the reference's two tables
     (experiments/acas.jl:146-185): `saveto` and `saveto + "-qdf.csv"`, re-saved after every pair."""
     rows, qrows = [], []
     for name, net, sname, spec in pairs:
-        solns, nq, status = verifyAcasSpec(net, spec, beta, opts, solve=solve, log=log, batch_clause=batch_clause)
+        solns, nq, status = verifyAcasSpec(net, spec, beta, opts, solve=solve, log=log, batch_clause=batch_clause, via_reach=via_reach)
         good = [s for s in solns if isSolutionGood(s)]
         avg = sum(s.total_time for s in good) / len(good) if good else float("inf")
         rows.append([name, sname, status, nq, len(solns), avg, sum(s.total_time for s in solns)])

@@ -162,3 +162,56 @@ def test_clause_literals_in_one_batch_on_gpu():
     # clause 1: "Y_0 <= 10" cannot be refuted (it is true), "Y_1 >= 20" can; clause 2: "Y_0 >= 15" can
     assert (nq, nq2, st1, st2) == (4, 4, "safe", "safe")
     assert len(s1) == 3 and len(s2) == 4
+
+
+def test_reach_form_of_a_safety_literal_cpu():
+    """reachForm / safetyFromReach: the hyperplane literal becomes a reach query on the same normal over a network whose
+    output bias is shifted by a lower bound h0 of normal' y (the offset multiplier of a reach query is >= 0); a reach
+    solution turns into the safety certificate Z_safety = Z_reach - 2 (h - rho) e_a e_a', rho = objective + h0."""
+    net = _net([2, 6, 6, 3])
+    (qin, qsafe), = vl.loadVnnlibCnf("(assert (>= X_0 0))(assert (<= X_0 1))(assert (>= X_1 0))(assert (<= X_1 1))(assert (>= Y_1 2.5))", net)[0]
+    qa = na.makeQcActivs(net, qin.x1min, qin.x1max, 0)
+    sq = na.SafetyQuery(ffnet=net, qc_input=qin, qc_safety=qsafe, qc_activs=qa)
+    rq, h, h0 = vl.reachForm(sq)
+    assert np.array_equal(rq.qc_reach.normal, [0.0, 1.0, 0.0]) and h == pytest.approx(2.5 - 1e-4)
+    X = np.random.default_rng(0).random((2, 4000))
+    y1 = na.evalFeedFwdNet(net, X)[1]
+    assert h0 <= y1.min() and np.allclose(na.evalFeedFwdNet(rq.ffnet, X)[1], y1 - h0) and rq.ffnet is not net
+    assert np.array_equal(rq.ffnet.Ms[0], net.Ms[0]) and np.array_equal(rq.ffnet.Ms[-1][:, :-1], net.Ms[-1][:, :-1])
+    n = sum(net.xdims) + 1
+    vals = {"γin": np.ones(2), "γout": np.array([2.0]), "γac1": np.ones(12), "γac2": np.ones(36), "Z": -np.eye(n)}
+    s = vl.safetyFromReach(na.QuerySolution(2.0 - h0, dict(vals), "OPTIMAL", 1.0, 0.1, 0.9, {"lambda_max": -1.0}), h, h0)
+    assert s.termination_status == "OPTIMAL" and vl.isSolutionGood(s) and "γout" not in s.values
+    assert s.values["Z"][-1, -1] == pytest.approx(-1.0 - 2 * (h - 2.0)) and s.summary["margin"] == pytest.approx(h - 2.0)
+    assert s.objective_value == pytest.approx(2 + 12 + 36)
+    bad = vl.safetyFromReach(na.QuerySolution(4.0 - h0, dict(vals), "OPTIMAL", 1.0, 0.1, 0.9, {"lambda_max": -1.0}), h, h0)
+    assert bad.termination_status == "INFEASIBLE" and bad.summary["margin"] < 0 and not vl.isSolutionGood(bad)
+    Sc = qsafe.S.copy(); Sc[0, 0] = 1.0
+    with pytest.raises(ValueError):
+        vl.reachForm(na.SafetyQuery(ffnet=net, qc_input=qin, qc_safety=na.QcSafety(S=Sc), qc_activs=qa))
+
+
+@pytest.mark.gpu
+def test_via_reach_agrees_and_fails_fast_on_gpu():
+    d = helpers.load_problem("W10-D5", 0)
+    net = na.FeedFwdNet(xdims=[int(v) for v in d["xdims"]], Ms=helpers.problem_Ms(d))
+    spec = os.path.join(SPEC, "prop_bound.vnnlib")
+    opts = na.AdmmSdpOptions(max_iters=100000, eps_rel=1e-6, cert_tol=1e-3)
+    s1, _, st1 = vl.verifyAcasSpec(net, spec, 1, opts)
+    s2, _, st2 = vl.verifyAcasSpec(net, spec, 1, opts, via_reach=True)
+    assert st1 == st2 == "safe" and s2[0].summary["margin"] > 0
+    Z = s2[0].values["Z"]
+    assert np.linalg.eigvalsh(0.5 * (Z + Z.T))[-1] <= vl.NSD_TOL and all(np.all(s2[0].values[k] >= 0) for k in ("γin", "γac1", "γac2"))
+    # the certified bound of the reach form is the threshold of the safety form: just above it the property is certified,
+    # just below it is not - and the reach form says so in bounded time
+    bound = s2[0].summary["reach_bound"]
+    box = "(assert (>= X_0 0.5))(assert (<= X_0 1.5))(assert (>= X_1 0.5))(assert (<= X_1 1.5))"
+    ok, _, st_ok = vl.verifyAcasSpec(net, box + f"(assert (>= Y_0 {bound + 0.01}))", 1, opts, via_reach=True)
+    no, _, st_no = vl.verifyAcasSpec(net, box + f"(assert (>= Y_0 {bound - 0.02 * max(1.0, abs(bound))}))", 1, opts, via_reach=True)
+    assert (st_ok, st_no) == ("safe", "unsafe") and no[0].termination_status == "INFEASIBLE" and no[0].summary["margin"] < 0
+    assert no[0].summary["iters"] == ok[0].summary["iters"]
+    # the bound is a genuine maximum estimate (this network's first output is negative on the box: without the bias shift the
+    # reach form could only return gamma_out = 0)
+    X = 0.5 + np.random.default_rng(0).random((2, 20000))
+    y0 = na.evalFeedFwdNet(net, X)[0]
+    assert y0.max() <= bound <= y0.max() + 0.5 * (y0.max() - y0.min()) + 0.05
