@@ -75,9 +75,7 @@ typedef struct nnsdp_options {
   double alpha;           /* over-relaxation in (0,2) */
   int32_t adapt_every;    /* residual-balancing period, iterations; 0 = fixed sigma */
   int32_t check_every;    /* convergence-check period, iterations (= iterations per hipGraph launch) */
-  int32_t normalize;      /* 1: solver-internal interval congruence + fixed-neuron elimination in reach queries (default);
-                           * 2: eliminate fixed neurons in safety queries too (feasibility mode for verification drivers:
-                           *    the certificate is valid, the objective sum(gamma) is not the reference's optimum) */
+  int32_t normalize;      /* 1: solver-internal interval congruence + fixed-neuron elimination (reach queries) (default) */
   int32_t warm_start;     /* 1: warm-start each eigendecomposition from the previous eigenvectors */
   double proj_tol;        /* Jacobi stops at off(A) <= proj_tol |A|_F; 0 = adaptive: 0.01 x the current residual,
                              clamped to [1e-9, 1e-4] (inexact projections well below the residual level) */

@@ -264,7 +264,7 @@ struct nnsdp_solver {
     require_gpu();
     if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
     HIPCHK(hipStreamCreate(&st));
-    C = make_congruence(P, opt.normalize != 0, opt.normalize >= 2);
+    C = make_congruence(P, opt.normalize != 0);
     auto cl_full = clique_index_sets(P.K, P.xdims.data(), P.beta, opt.decomp_mode);
     std::vector<std::vector<int>> cl;
     for (auto& cq : cl_full) {
@@ -797,7 +797,7 @@ struct nnsdp_solver {
       full->build(&pp);
     }
     std::vector<int> elim;  // neurons removed by the normalisation: gac1 -> "large enough"
-    if (opt.normalize && (P.query_kind == NNSDP_QUERY_REACH || opt.normalize >= 2))
+    if (opt.normalize && P.query_kind == NNSDP_QUERY_REACH)
       for (int t = 0; t < P.acdim; ++t)
         if (C.newpos[P.nin + t] < 0) elim.push_back(t);
     DBuf<double> Zd;

@@ -225,9 +225,7 @@ struct Congruence {
   }
 };
 
-// eliminate_always: also in safety queries (normalize = 2), where the multipliers that pin a fixed neuron are not cost-free -
-// a feasibility mode for verification drivers (the objective of the returned point is then not the reference's optimum)
-inline Congruence make_congruence(const ProblemCopy& P, bool normalize, bool eliminate_always = false) {
+inline Congruence make_congruence(const ProblemCopy& P, bool normalize) {
   Congruence C;
   C.nfull = P.Zdim;
   C.m.assign(P.Zdim - 1, 0.0);
@@ -238,7 +236,7 @@ inline Congruence make_congruence(const ProblemCopy& P, bool normalize, bool eli
     C.nred = P.Zdim;
     return C;
   }
-  bool eliminate = (P.query_kind == NNSDP_QUERY_REACH) || eliminate_always;  // only cost-free multipliers may go to infinity
+  bool eliminate = (P.query_kind == NNSDP_QUERY_REACH);  // only cost-free multipliers may go to infinity
   double hmax = 0.0;
   for (int i = 0; i < P.Zdim - 1; ++i) {
     double lo = i < P.nin ? P.x1min[i] : P.acymin[i - P.nin];

@@ -187,7 +187,6 @@ class AdmmSdpOptions:
     adapt_every: int = 50
     check_every: int = 50
     normalize: bool = True
-    eliminate_fixed: bool = False  # safety queries: also drop neurons with a zero-width interval (feasibility mode, see include/nnsdp.h)
     warm_start: bool = True
     proj_tol: float = 0.0          # 0 = adaptive (see include/nnsdp.h)
     polish: bool = True            # exact-feasibility polish of the returned certificate
@@ -206,7 +205,7 @@ class AdmmSdpOptions:
         o.alpha = float(self.alpha)
         o.adapt_every = int(self.adapt_every)
         o.check_every = int(self.check_every)
-        o.normalize = (2 if self.eliminate_fixed else 1) if self.normalize else 0
+        o.normalize = int(bool(self.normalize))
         o.warm_start = int(bool(self.warm_start))
         o.proj_tol = float(self.proj_tol)
         o.polish = int(bool(self.polish))

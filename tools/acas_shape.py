@@ -19,8 +19,8 @@ spec = "".join(f"(assert (>= X_{i} {x0[i] - 0.05}))(assert (<= X_{i} {x0[i] + 0.
 xi, acx = na.makeIntervalsInfo(x0 - 0.05, x0 + 0.05, net)
 dead = sum(int(np.sum(u <= 0)) for l, u in xi[1:-1])
 print(f"W={W}: y0={y0[0]:.4f}, output interval [{xi[-1][0][0]:.4f}, {xi[-1][1][0]:.4f}], fixed (dead) hidden neurons {dead} of {6 * W}")
-for elim, mode, via in ((False, na.PathDecomp(), False), (False, na.PathDecomp(), True)):
-    opts = na.AdmmSdpOptions(decomp_mode=mode, max_iters=60000, eps_rel=1e-5, eliminate_fixed=elim, max_time=120, cert_tol=1e-3 if via else 0.0)
+for mode, via in ((na.PathDecomp(), False), (na.PathDecomp(), True)):
+    opts = na.AdmmSdpOptions(decomp_mode=mode, max_iters=60000, eps_rel=1e-5, max_time=120, cert_tol=1e-3 if via else 0.0)
     t = time.time()
     try:
         solns, nq, status = vl.verifyAcasSpec(net, spec, 1, opts, via_reach=via)
