@@ -28,4 +28,4 @@ for mode, via in ((na.PathDecomp(), False), (na.PathDecomp(), True)):
         print(f"via_reach={via} {type(mode).__name__}: margin {s.summary.get('margin')} {status} {s.termination_status} iters {s.summary['iters']} blocks {s.summary['n_cliques']} max {s.summary['max_clique']} "
               f"lambda_max {s.summary['lambda_max']:.2e} solve {s.solve_time:.2f}s wall {time.time() - t:.2f}s sweeps {s.summary['avg_sweeps']:.2f}", flush=True)
     except Exception as e:
-        print(f"eliminate_fixed={elim} {type(mode).__name__}: {type(e).__name__}: {e}", flush=True)
+        print(f"via_reach={via} {type(mode).__name__}: {type(e).__name__}: {e}", flush=True)
