@@ -18,6 +18,7 @@ sub-query one SDP through runQuery.
 from __future__ import annotations
 
 import csv
+import dataclasses
 import os
 import re
 from dataclasses import dataclass
@@ -269,7 +270,8 @@ def verifyAcasSpec(net: M.FeedFwdNet, spec, beta: int, opts: M.AdmmSdpOptions,
     soon as a clause has none (experiments/acas.jl:87-137).  -> (solutions tried, number of queries, status).
     batch_clause: the sub-queries of a clause are independent SDPs on one network - solve them in lockstep through the
     batch handle (runQueries) instead of one after the other; every literal of a tried clause then counts as run.
-    via_reach: decide every literal through the equivalent reach-hyperplane query (reachForm / safetyFromReach) - the
+    via_reach: True = decide every literal through the equivalent reach-hyperplane query (reachForm / safetyFromReach);
+    "auto" = first give the feasibility form 500 iterations per literal (failed attempts are not recorded).  The
     feasibility form 'min sum(gamma)' of the reference needs an interior-point solver to FAIL quickly; the reach form
     ends in bounded time either way and reports the margin."""
     solve = solve or M.solveQuery
@@ -278,6 +280,21 @@ def verifyAcasSpec(net: M.FeedFwdNet, spec, beta: int, opts: M.AdmmSdpOptions,
     solns, status = [], "safe"
     for ci, clause in enumerate(cnf):
         holds = False
+        auto = via_reach == "auto"
+        if auto:
+            # a comfortably certifiable literal is decided by the feasibility form within a few hundred iterations;
+            # everything else goes to the reach form, which ends in bounded time either way
+            quick = dataclasses.replace(opts, max_iters=min(int(opts.max_iters), 500), cert_tol=0.0)
+            for qi, q in enumerate(clause):
+                s = solve(q, quick)
+                if isSolutionGood(s):
+                    solns.append(s)
+                    holds = True
+                    if log:
+                        log(f"conj {ci + 1}/{len(cnf)} subquery {qi + 1}/{len(clause)}: certified by the feasibility form in {s.summary.get('iters')} iterations")
+                    break
+            if holds:
+                continue
         forms = [reachForm(q) for q in clause] if via_reach else [(q, None, None) for q in clause]
         if batch_clause and len(clause) > 1:
             got = M.runQueries([f[0] for f in forms], opts)

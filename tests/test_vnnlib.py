@@ -209,6 +209,10 @@ def test_via_reach_agrees_and_fails_fast_on_gpu():
     ok, _, st_ok = vl.verifyAcasSpec(net, box + f"(assert (>= Y_0 {bound + 0.01}))", 1, opts, via_reach=True)
     no, _, st_no = vl.verifyAcasSpec(net, box + f"(assert (>= Y_0 {bound - 0.02 * max(1.0, abs(bound))}))", 1, opts, via_reach=True)
     assert (st_ok, st_no) == ("safe", "unsafe") and no[0].termination_status == "INFEASIBLE" and no[0].summary["margin"] < 0
+    au, _, st_au = vl.verifyAcasSpec(net, spec, 1, opts, via_reach="auto")        # Y_0 <= 10: comfortable -> feasibility form
+    au2, _, st_au2 = vl.verifyAcasSpec(net, box + f"(assert (>= Y_0 {bound - 0.02 * max(1.0, abs(bound))}))", 1, opts, via_reach="auto")   # not certifiable -> reach form
+    assert st_au == "safe" and "margin" not in au[0].summary and au[0].summary["iters"] <= 500
+    assert st_au2 == "unsafe" and len(au2) == 1 and au2[0].summary["margin"] < 0
     assert no[0].summary["iters"] == ok[0].summary["iters"]
     # the bound is a genuine maximum estimate (this network's first output is negative on the box: without the bias shift the
     # reach form could only return gamma_out = 0)
