@@ -51,6 +51,20 @@ def evalFeedFwdNet(net: M.FeedFwdNet, x) -> np.ndarray:
     return xk[:, 0] if vec else xk
 
 
+def randomNetwork(xdims: Sequence[int], sigma: float = None, seed: int = 1234) -> M.FeedFwdNet:
+    """Utils.randomNetwork (src/Utils/Utils.jl:22-26): every [W_k b_k] entry i.i.d. N(0, sigma^2).  Default sigma is the
+    scaling experiments' 2 / sqrt(W ln W) with W the hidden width (scripts/make_networks.jl:43-46); numpy's generator, the
+    Julia stream of the reference cannot be reproduced."""
+    xdims = [int(v) for v in xdims]
+    if len(xdims) < 2 or min(xdims) <= 0:
+        raise ValueError("xdims needs at least two positive entries")
+    if sigma is None:
+        width = max(xdims[1:-1]) if len(xdims) > 2 else max(xdims)
+        sigma = 2.0 / np.sqrt(width * np.log(width)) if width > 1 else 1.0
+    rng = np.random.default_rng(seed)
+    return M.FeedFwdNet(xdims=xdims, Ms=[rng.normal(0.0, sigma, size=(xdims[k + 1], xdims[k] + 1)) for k in range(len(xdims) - 1)])
+
+
 # ----------------------------------------------------------------------------- f1: CROWN-sliced intervals
 def _intervals_native(x1min, x1max, net: M.FeedFwdNet):
     """nnsdp_make_intervals (host C++ in the library, csrc/intervals.hpp): replaces the reference's per-layer

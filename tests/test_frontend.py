@@ -160,3 +160,13 @@ def test_run_scale_beta_sweep_batched(tmp_path):
         assert pub and min(abs(s.objective_value - p) / abs(p) for p in pub) <= 1e-3
     got = list(csv.reader(open(out)))
     assert got[0] == ["beta", "setup_secs", "solve_secs", "total_secs", "obj_val", "term_status", "eigmax"] and [r[0] for r in got[1:]] == ["0", "3", "7"]
+
+
+def test_random_network_distribution():
+    net = na.randomNetwork([2, 40, 40, 40, 2], seed=3)
+    ref = nnet_io.random_net([2, 40, 40, 40, 2], seed=3)            # the oracle's generator: same stream, same scale
+    assert all(np.array_equal(a, b) for a, b in zip(net.Ms, ref.Ms))
+    assert abs(np.std(np.concatenate([m.ravel() for m in net.Ms])) - 2 / np.sqrt(40 * np.log(40))) < 0.01
+    assert np.std(na.randomNetwork([3, 8, 2], sigma=0.5, seed=1).Ms[0]) == pytest.approx(0.5, rel=0.3)
+    with pytest.raises(ValueError):
+        na.randomNetwork([3])

@@ -6,10 +6,8 @@ for p in (ROOT, os.path.join(ROOT, "nn-sdp_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np
 import nnsdp_amd as na
-from oracle import nnet_io
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-n = nnet_io.random_net([5] + [W] * 6 + [5], seed=1234)
-net = na.FeedFwdNet(xdims=list(n.xdims), Ms=n.Ms)
+net = na.randomNetwork([5] + [W] * 6 + [5], seed=1234)
 x0 = np.full(5, 0.3)
 lo, hi = x0 - 0.05, x0 + 0.05
 xi, _ = na.makeIntervalsInfo(lo, hi, net)

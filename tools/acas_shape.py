@@ -8,11 +8,9 @@ for p in (ROOT, os.path.join(ROOT, "nn-sdp_amd"), os.path.join(ROOT, "tests")):
 import numpy as np
 import nnsdp_amd as na
 from nnsdp_amd import vnnlib as vl
-from oracle import nnet_io
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 margin = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-n = nnet_io.random_net([5] + [W] * 6 + [5], seed=1234)
-net = na.FeedFwdNet(xdims=list(n.xdims), Ms=n.Ms)
+net = na.randomNetwork([5] + [W] * 6 + [5], seed=1234)
 x0 = np.full(5, 0.3)
 y0 = na.evalFeedFwdNet(net, x0)
 spec = "".join(f"(assert (>= X_{i} {x0[i] - 0.05}))(assert (<= X_{i} {x0[i] + 0.05}))" for i in range(5)) + f"(assert (>= Y_0 {y0[0] + margin}))"
