@@ -209,7 +209,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   constexpr bool BLOCK = ALG == 1;
   constexpr bool SYS = ALG == 2;
   constexpr bool PP = ALG == 3;
-  static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
+  static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 5 || RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // Jacobi dimension (even)
@@ -512,7 +512,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     // by at most 0.7^np, far inside the fp64 range).  The scales live in the parameter wave; the true values are
     // restored at the end of every sweep, where convergence is measured.
     constexpr int UW = NT / 64 - 1;            // updater waves
-    constexpr int VRW = RPW;                   // eigenvector rows per updater wave (6: n <= 90, 7: n <= 96), dealt round robin
+    constexpr int VRW = RPW;                   // eigenvector rows per updater wave (5: n <= 74, 6: n <= 90, 7: n <= 96), dealt round robin
     constexpr int MAXI = 2;                    // items per updater thread: (m+1)(m+2)/2 <= 1225 <= 2 x 960
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1279,12 +1279,13 @@ inline bool proj_sys_ok(int nmax) { return nmax >= kSysMin && nmax <= 128; }
 inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   // V in LDS, 1024 threads
 #define NNSDP_PROJ_VARIANTS(X) \
   X((k_proj_jacobi<true, 1024, 1>)) X((k_proj_jacobi<true, 256, 1>)) X((k_proj_jacobi<true, 1024>)) X((k_proj_jacobi<false, 1024>)) \
-  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<false, 512, 2, 7, 14>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>)) \
+  X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<false, 512, 2, 7, 14>)) X((k_proj_jacobi<true, 1024, 3, 1, 5>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>)) \
   X((k_proj_jacobi_b<true, 1024>)) X((k_proj_jacobi_b<false, 1024>)) X((k_proj_jacobi_b<true, 256>)) X((k_proj_jacobi_b<false, 256>)) \
-  X((k_proj_jacobi_b<true, 512, 2, 6, 12>)) X((k_proj_jacobi_b<false, 512, 2, 8, 16>)) X((k_proj_jacobi_b<false, 512, 2, 7, 14>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 6>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 7>))
+  X((k_proj_jacobi_b<true, 512, 2, 6, 12>)) X((k_proj_jacobi_b<false, 512, 2, 8, 16>)) X((k_proj_jacobi_b<false, 512, 2, 7, 14>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 5>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 6>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 7>))
 inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
-    if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
+    if (nmax <= 74) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 5>), dim3(nblocks), dim3(1024), lds, st, a);
+    else if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 7>), dim3(nblocks), dim3(1024), lds, st, a);
     return;
   }
@@ -1311,7 +1312,8 @@ inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, si
 inline void launch_proj_batched(const ProjArgs* dargs, const int2* dmap, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st,
                                 int alg) {
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
-    if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
+    if (nmax <= 74) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 5>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
+    else if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
     else hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 7>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
     return;
   }
