@@ -110,3 +110,23 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "oracle/" not in src or f.endswith(".md"), f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """the boundary from the other side: include/nnsdp.h compiles as C99 (-pedantic) and the host-only entry points run from
+    a C program linked against the library (what a cgo / ccall / JNI binding does)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = _lib.LIB_PATH
+    if not os.path.exists(lib):
+        pytest.fail("libnnsdp_hip.so is not built")
+    exe = str(tmp_path / "abi_check")
+    src = os.path.join(helpers.ROOT, "tests", "c_abi", "abi_check.c")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(helpers.ROOT, "include"), src, "-o", exe, lib,
+           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
