@@ -572,11 +572,12 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     // pair's first / second position before the round
     // (the parameter wave holds no eigenvector rows: its state lives in those registers, the kernel runs at the VGPR limit)
     double &st_pp = vr[0][0], &st_qq = vr[0][1], &st_pq = vr[1][0], &pc = vr[1][1], &ps = vr[2][0], &st_dp = vr[2][1], &st_dq = vr[3][0];
+    // off(A)^2 before the first sweep; afterwards it comes out of the pass that restores the true values
+    double off2 = 0.0;
+    for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
+      for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[pidx(i, j, 1)]; off2 += v * v; }
+    off2 = 2.0 * block_sum(off2, red);
     for (;;) {
-      double off2 = 0.0;
-      for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
-        for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[pidx(i, j, 1)]; off2 += v * v; }
-      off2 = 2.0 * block_sum(off2, red);
       if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
       if (!updater) {   // rotations of round 0 (type 0) straight from the matrix, all scales 1
         st_dp = 1.0; st_dq = 1.0;
@@ -727,17 +728,22 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         round(std::integral_constant<int, 0>{}, t);
         round(std::integral_constant<int, 1>{}, t + 1);
       }
-      // back to true values: A_ij = d_i d_j a_ij, V_ij = d_j v_ij
+      // back to true values: A_ij = d_i d_j a_ij, V_ij = d_j v_ij; the same pass measures off(A)^2 for the next decision
+      off2 = 0.0;
       for (int i = (tid >> 6) + 1; i <= np; i += NT >> 6) {
         const double di = dsc[i - 1];
-        for (int j = (tid & 63) + 1; j <= i; j += 64) B0[pidx(i, j, 1)] *= di * dsc[j - 1];
+        for (int j = (tid & 63) + 1; j <= i; j += 64) {
+          const double v = B0[pidx(i, j, 1)] * (di * dsc[j - 1]);
+          B0[pidx(i, j, 1)] = v;
+          if (j < i) off2 += v * v;
+        }
       }
       if (lane < m) {
         const double da = dsc[2 * lane], db = dsc[2 * lane + 1];
 #pragma unroll
         for (int j = 0; j < VRW; ++j) { vr[j][0] *= da; vr[j][1] *= db; }
       }
-      __syncthreads();
+      off2 = 2.0 * block_sum(off2, red);     // (two barriers: the rescaled matrix is visible to everybody afterwards)
       ++sweeps;
     }
     // ---- eigenvalues back to the unshifted diagonal of A, eigenvectors (position order) to V
@@ -1264,8 +1270,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) { proj_body<V_LD
 template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
 __global__ __launch_bounds__(NT) void k_proj_jacobi_b(const ProjArgs* __restrict__ args, const int2* __restrict__ map) {
   const int2 m = map[blockIdx.x];
-  const ProjArgs a = args[m.x];
-  proj_body<V_LDS, NT, ALG, SPW, RPW>(a, m.y);
+  const int sdp = __builtin_amdgcn_readfirstlane(m.x), blk = __builtin_amdgcn_readfirstlane(m.y);   // wave-uniform: keep the arguments in SGPRs
+  const ProjArgs a = args[sdp];
+  proj_body<V_LDS, NT, ALG, SPW, RPW>(a, blk);
 }
 
 // launch: projection algorithm by the largest block of the launch.
