@@ -50,23 +50,9 @@ def cpu_baseline(workload: str, beta: int, seconds: float):
     q = helpers.oracle_query(d)
     L = oop.build_operator(q, "single", normalize=True)
 
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(cores)
-
     def run():
         P = oadmm.ScaledProblem(L)
         S = oadmm.AdmmState(P, 0.1, 1.6)
-
-        def proj_parallel(nu):      # the oracle's projection step, cliques in parallel (LAPACK releases the GIL), one BLAS thread each
-            w = np.empty_like(nu)
-            w[:S.ng] = np.maximum(nu[:S.ng], 0.0)
-
-            def one(k):
-                n = S.nk[k]
-                w[S.offs[k]:S.offs[k + 1]] = oadmm.project_psd(nu[S.offs[k]:S.offs[k + 1]].reshape(n, n)).ravel()
-            list(pool.map(one, range(len(S.nk))))
-            return w
-        S.proj = proj_parallel
         for _ in range(3):
             S.step()
         n, t0 = 0, time.time()
@@ -75,13 +61,12 @@ def cpu_baseline(workload: str, beta: int, seconds: float):
             n += 1
         return n, time.time() - t0
     if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
+        with threadpool_limits(limits=cores):
             n, dt = run()
     else:
         n, dt = run()
-    pool.shutdown()
     return {"value": n / dt, "unit": "ADMM iters/s", "cores": cores, "kind": "port",
-            "sample": f"{n} iterations of the numpy oracle ADMM (oracle/admm.py, LAPACK eigh per clique, cliques in parallel on {cores} threads) on {workload} beta={beta} in {dt:.1f} s"}
+            "sample": f"{n} iterations of the numpy oracle ADMM (oracle/admm.py, LAPACK eigh per clique) on {workload} beta={beta} in {dt:.1f} s"}
 
 
 def main():
