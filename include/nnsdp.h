@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNSDP_VERSION 100 /* 0.1.0 */
+#define NNSDP_VERSION 200 /* 0.2.0 */
 
 /* query_kind: Methods.SafetyQuery / Methods.ReachQuery (src/Methods/Methods.jl:22-43) */
 enum { NNSDP_QUERY_SAFETY = 0, NNSDP_QUERY_REACH = 1 };
@@ -84,6 +84,12 @@ typedef struct nnsdp_options {
                              cert_tol (relative) of the ADMM primal/dual objective estimates; 0 = residual test only */
   int32_t verbose;        /* QueryOptions.verbose (src/Methods/Methods.jl:110) */
   int32_t device;         /* HIP device ordinal, -1 = current */
+  double interval_guard;  /* (normalize = 1) a neuron interval [acymin, acymax] narrower than interval_guard x |midpoint| is
+                             widened to that inside the solver (default 5e-5; 0 = take the bounds literally).  The returned
+                             gamma stays feasible for the LMI with the caller's bounds.  The reference's float32 CROWN
+                             boxes of collapsed deep nets are narrower than their own rounding error and, taken
+                             literally, make the QC set empty (rho = 0 would be "optimal"); MOSEK at 1e-6 never
+                             resolves that, an exact solver does. */
 } nnsdp_options;
 
 /* Contents of Methods.QuerySolution (src/Methods/Methods.jl:46-55) plus solver diagnostics.

@@ -9,8 +9,11 @@
 
 const LIBNNSDP = get(ENV, "NNSDP_LIB", "libnnsdp_hip.so")
 
+# extension: cliques {x_k, x_{k+1}, affine index}; exact whenever the output QC has no x_1 -- x_K coupling (S12 = 0)
+struct PathDecomp <: DecompMode end
+
 @with_kw struct AdmmSdpOptions <: QueryOptions
-  decomp_mode::DecompMode = SingleDecomp()   # SingleDecomp / DoubleDecomp (chordal_sdp.jl:4-8)
+  decomp_mode::DecompMode = SingleDecomp()   # SingleDecomp / DoubleDecomp / DoubleRelaxDecomp (chordal_sdp.jl:4-8) / PathDecomp
   dense::Bool = false                        # true: one dense cone (DeepSdpOptions behaviour)
   max_iters::Int = 20000
   eps_rel::Float64 = 1e-6
@@ -26,6 +29,7 @@ const LIBNNSDP = get(ENV, "NNSDP_LIB", "libnnsdp_hip.so")
   cert_tol::Float64 = 0.0
   verbose::Bool = false
   device::Int = -1
+  interval_guard::Float64 = 5e-5
 end
 
 # field order and types must match include/nnsdp.h
@@ -39,7 +43,7 @@ end
 struct COptions
   decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
   adapt_every::Int32; check_every::Int32; normalize::Int32; warm_start::Int32; proj_tol::Float64
-  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32
+  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32; interval_guard::Float64
 end
 mutable struct CResult
   gamma_in::Ptr{Float64}; gamma_out::Ptr{Float64}; gamma_ac1::Ptr{Float64}; gamma_ac2::Ptr{Float64}; Z::Ptr{Float64}
@@ -73,9 +77,16 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   Zdim = sum(ffnet.zdims)
   gin = zeros(query.qc_input.vardim); gout = zeros(1); gac1 = zeros(qb.vardim); gac2 = zeros(qs.vardim)
   Z = zeros(Zdim, Zdim)
-  mode = opts.dense ? Int32(0) : (opts.decomp_mode isa SingleDecomp ? Int32(1) : Int32(2))
+  # DoubleRelaxDecomp is treated exactly like DoubleDecomp by the reference (chordal_sdp.jl:25)
+  mode = opts.dense ? Int32(0) : opts.decomp_mode isa SingleDecomp ? Int32(1) : opts.decomp_mode isa PathDecomp ? Int32(3) : Int32(2)
+  # obj_func (Methods.jl:41) is affine in γout[1] at every call site (x -> x[1], NnSdp.jl:46,66,87); any increasing affine
+  # a*ρ + b has the same minimiser, so it is evaluated on the solution instead of being handed to the solver
+  if query isa ReachQuery
+    f0, f1 = query.obj_func([0.0]), query.obj_func([1.0])
+    f1 > f0 || error("obj_func must be increasing in γout[1]")
+  end
   copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
-                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device)
+                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device, opts.interval_guard)
   res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
                 0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0)
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin
@@ -92,7 +103,8 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
     println("setup: $(round(res.t_setup, digits=3)) \tsolve: $(round(res.t_solve, digits=3)) \ttotal: $(round(res.t_total, digits=3)) \t" *
             "obj: $(round(res.objective, digits=5)) ($(status)) \tλmax: $(round(res.lambda_max, digits=7))")
   end
-  return QuerySolution(model = nothing, objective_value = res.objective, values = values, summary = res,
+  objval = query isa ReachQuery ? query.obj_func(gout) : res.objective
+  return QuerySolution(model = nothing, objective_value = objval, values = values, summary = res,
                        termination_status = status, total_time = res.t_total, setup_time = res.t_setup, solve_time = res.t_solve)
 end
 

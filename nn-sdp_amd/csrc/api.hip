@@ -264,7 +264,8 @@ struct nnsdp_solver {
     require_gpu();
     if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
     HIPCHK(hipStreamCreate(&st));
-    C = make_congruence(P, opt.normalize != 0);
+    if (!(opt.interval_guard >= 0.0 && opt.interval_guard < 0.1)) throw std::invalid_argument("interval_guard must be in [0, 0.1)");
+    C = make_congruence(P, opt.normalize != 0, opt.interval_guard);
     auto cl_full = clique_index_sets(P.K, P.xdims.data(), P.beta, opt.decomp_mode);
     std::vector<std::vector<int>> cl;
     for (auto& cq : cl_full) {
@@ -359,10 +360,12 @@ struct nnsdp_solver {
     DBuf<rocblas_int> info;
     info.alloc(1);
     RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
+    HIPCHK(hipStreamSynchronize(st));
+    if (info.download()[0] != 0) throw HipError("Cholesky of M = I + A'D^-1A failed (potrf info != 0)");
     RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
     hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(ng, 256), ng), dim3(256), 0, st, ng, ldm, Minv.p);
     HIPCHK(hipStreamSynchronize(st));
-    if (info.download()[0] != 0) throw HipError("Cholesky of M = I + A'D^-1A failed (info != 0)");
+    if (info.download()[0] != 0) throw HipError("inverse of M = I + A'D^-1A failed (potri info != 0)");
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
     x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
@@ -796,10 +799,13 @@ struct nnsdp_solver {
       nnsdp_problem pp = problem_view();
       full->build(&pp);
     }
-    std::vector<int> elim;  // neurons removed by the normalisation: gac1 -> "large enough"
-    if (opt.normalize && P.query_kind == NNSDP_QUERY_REACH)
+    std::vector<int> elim;  // coordinates removed by the normalisation (full gamma index of their box multiplier): -> "large enough"
+    if (opt.normalize && P.query_kind == NNSDP_QUERY_REACH) {
+      for (int i = 0; i < P.nin; ++i)
+        if (C.newpos[i] < 0) elim.push_back(i);                       // degenerate input box x1min[i] == x1max[i]
       for (int t = 0; t < P.acdim; ++t)
-        if (C.newpos[P.nin + t] < 0) elim.push_back(t);
+        if (C.newpos[P.nin + t] < 0) elim.push_back(P.nin + P.nout + t);
+    }
     DBuf<double> Zd;
     double lmax = 0;
     double gscale = 1.0;
@@ -809,15 +815,15 @@ struct nnsdp_solver {
     int ntrial = elim.empty() ? 1 : 6;
     for (int trial = 0; trial < ntrial; ++trial) {
       double big = elim.empty() ? 0.0 : gscale * std::pow(100.0, trial + 1);
-      for (int t : elim) gam[P.nin + P.nout + t] = big;
+      for (int t : elim) gam[t] = big;
       full->assemble(gam, Zd, st);
       lmax = lambda_max_dense(roc->h, Zd, P.Zdim);
       if (lmax < best_l) { best_l = lmax; best_big = big; }
       if (lmax <= 1e-7 || (trial > 0 && lmax >= 0.9 * prev_l)) break;
       prev_l = lmax;
     }
-    if (!elim.empty() && gam[P.nin + P.nout + elim[0]] != best_big) {
-      for (int t : elim) gam[P.nin + P.nout + t] = best_big;
+    if (!elim.empty() && gam[elim[0]] != best_big) {
+      for (int t : elim) gam[t] = best_big;
       full->assemble(gam, Zd, st);
       lmax = lambda_max_dense(roc->h, Zd, P.Zdim);
     }
@@ -1093,6 +1099,7 @@ void nnsdp_default_options(nnsdp_options* o) {
   o->cert_tol = 0.0;
   o->verbose = 0;
   o->device = -1;
+  o->interval_guard = 5e-5;
 }
 
 int nnsdp_problem_dims(const nnsdp_problem* p, int32_t* Zdim, int32_t* acdim, int32_t* nac2, int32_t* ngamma) {

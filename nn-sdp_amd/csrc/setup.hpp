@@ -206,6 +206,7 @@ struct Congruence {
   std::vector<double> m, h;
   std::vector<int> newpos;
   int nfull = 0, nred = 0;
+  bool factored = false;   // true: box generators are written in their exact factored form -2 h^2 (zhat_i^2 - zhat_a^2)
   SpVec tvec(const SpVec& v) const {
     SpVec o;
     double acc = 0.0;
@@ -225,7 +226,12 @@ struct Congruence {
   }
 };
 
-inline Congruence make_congruence(const ProblemCopy& P, bool normalize) {
+// `guard` (nnsdp_options.interval_guard): a neuron interval narrower than guard x |midpoint| is widened to that.  The
+// solver then works with the weaker, still valid, QC, and a gamma feasible for the widened LMI is feasible for the
+// original one: Z_orig(gamma) = Z_wid(gamma) - 2 gac1_t (h_wid^2 - h^2) e_a e_a'.  Needed because the reference's
+// float32 CROWN boxes of collapsed deep nets (bench/rand W10-D80, W20-D70, ...) are narrower than their own rounding
+// error: they exclude the float64 trajectories by up to 2e-5 relative, the QC set is then empty and rho = 0 "optimal".
+inline Congruence make_congruence(const ProblemCopy& P, bool normalize, double guard = 0.0) {
   Congruence C;
   C.nfull = P.Zdim;
   C.m.assign(P.Zdim - 1, 0.0);
@@ -243,8 +249,10 @@ inline Congruence make_congruence(const ProblemCopy& P, bool normalize) {
     double hi = i < P.nin ? P.x1max[i] : P.acymax[i - P.nin];
     C.m[i] = 0.5 * (lo + hi);
     C.h[i] = 0.5 * (hi - lo);
+    if (i >= P.nin) C.h[i] = std::max(C.h[i], guard * std::fabs(C.m[i]));
     hmax = std::max(hmax, C.h[i]);
   }
+  C.factored = true;
   if (!eliminate)
     for (auto& v : C.h) v = std::max(v, 1e-6 * std::max(1.0, hmax));
   int r = 0;
@@ -276,14 +284,22 @@ class OperatorBuilder {
     op_.ng = P.ng;
     int a = P.Zdim - 1;
     SpVec ea = C_.tvec(unit(a));
-    // gin (input.jl:24-26)
-    for (int i = 0; i < P.nin; ++i) {
-      double l = P.x1min[i], u = P.x1max[i];
-      SpVec ei = C_.tvec(unit(i));
-      add_sym(i, ei, ei, -1.0);
-      add_sym(i, ei, ea, l + u);
-      add_sym(i, ea, ea, -l * u);
-    }
+    // box generator -2 (z_i - l)(z_i - u) (input.jl:24-26, activ_bounded.jl:19-21); in solver coordinates it is
+    // exactly -2 h^2 (zhat_i^2 - zhat_a^2): written in that factored form, free of cancellation
+    auto add_box = [&](int gen, int i, double l, double u) {
+      if (!C_.factored) {
+        SpVec ei = C_.tvec(unit(i));
+        add_sym(gen, ei, ei, -1.0);
+        add_sym(gen, ei, ea, l + u);
+        add_sym(gen, ea, ea, -l * u);
+      } else if (C_.newpos[i] >= 0) {
+        const double hh = C_.h[i] * C_.h[i];
+        SpVec ri{{C_.newpos[i]}, {1.0}}, ra{{C_.nred - 1}, {1.0}};
+        add_sym(gen, ri, ri, -hh);
+        add_sym(gen, ra, ra, hh);
+      }
+    };
+    for (int i = 0; i < P.nin; ++i) add_box(i, i, P.x1min[i], P.x1max[i]);
     // gout (output.jl:75,84,93)
     if (P.nout) add_sym(P.nin, ea, ea, P.out_kind == NNSDP_OUT_HPLANE ? -1.0 : -0.5);
     // activations
@@ -302,10 +318,8 @@ class OperatorBuilder {
       }
     }
     for (t = 0; t < P.acdim; ++t) {
-      double l = P.acymin[t], u = P.acymax[t], sn = P.smin[t], sx = P.smax[t];
-      add_sym(o1 + t, yt[t], yt[t], -1.0);                 // activ_bounded.jl:19-21
-      add_sym(o1 + t, yt[t], ea, l + u);
-      add_sym(o1 + t, ea, ea, -l * u);
+      double sn = P.smin[t], sx = P.smax[t];
+      add_box(o1 + t, P.nin + t, P.acymin[t], P.acymax[t]);   // activ_bounded.jl:19-21
       add_sym(ol + t, ut[t], ut[t], -sn * sx);             // activ_sector.jl:42 (Q11)
       add_sym(ol + t, ut[t], yt[t], sn + sx);              // activ_sector.jl:43 (Q12)
       add_sym(oe + t, ut[t], ea, -sn);                     // activ_sector.jl:55

@@ -3,7 +3,7 @@ reference's Methods/Qc API over the C ABI in include/nnsdp.h)."""
 from .methods import (  # noqa: F401
     FeedFwdNet, QcInputBox, QcSafety, QcReachHplane, QcReachCircle, QcReachEllipsoid,
     QcActivBounded, QcActivSector, SafetyQuery, ReachQuery, AdmmSdpOptions, QuerySolution,
-    SingleDecomp, DoubleDecomp, PathDecomp, DenseCone, Solver, SolverBatch,
+    SingleDecomp, DoubleDecomp, DoubleRelaxDecomp, PathDecomp, DenseCone, Solver, SolverBatch,
     runQuery, runQueries, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched, comm_unique_id,
 )
 from .frontend import (  # noqa: F401
@@ -16,4 +16,4 @@ from .vnnlib import (  # noqa: F401
     read_vnnlib, hplaneS, loadVnnlibCnf, loadReluQueriesCnf, verifyAcasSpec, verifyPairs, isSolutionGood, shardPairs, reachForm, safetyFromReach,
 )
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -39,6 +39,7 @@ class Options(C.Structure):
         ("max_time", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
         ("adapt_every", C.c_int32), ("check_every", C.c_int32), ("normalize", C.c_int32),
         ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("polish", C.c_int32), ("cert_tol", C.c_double), ("verbose", C.c_int32), ("device", C.c_int32),
+        ("interval_guard", C.c_double),
     ]
 
 

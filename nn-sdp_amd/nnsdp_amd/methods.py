@@ -43,6 +43,9 @@ class PathDecomp:
     code = 3
 
 
+DoubleRelaxDecomp = DoubleDecomp   # the reference treats the two identically (src/Methods/chordal_sdp.jl:8,25)
+
+
 class DenseCone:
     """DeepSdpOptions' single dense cone (src/Methods/deep_sdp.jl:57)."""
     code = 0
@@ -193,6 +196,7 @@ class AdmmSdpOptions:
     cert_tol: float = 0.0          # > 0: early stop on the certified objective (see include/nnsdp.h)
     verbose: bool = False
     device: int = -1
+    interval_guard: float = 5e-5   # relative floor on neuron interval half-widths inside the solver (see include/nnsdp.h)
 
     def to_c(self) -> _lib.Options:
         o = _lib.Options()
@@ -212,6 +216,7 @@ class AdmmSdpOptions:
         o.cert_tol = float(self.cert_tol)
         o.verbose = int(bool(self.verbose))
         o.device = int(self.device)
+        o.interval_guard = float(self.interval_guard)
         return o
 
 
@@ -330,6 +335,17 @@ def _solution(cp: _CProblem, r, bufs) -> QuerySolution:
                          total_time=r.t_total, setup_time=r.t_setup, solve_time=r.t_solve, summary=summary)
 
 
+def _apply_obj_func(query, soln: QuerySolution) -> QuerySolution:
+    """ReachQuery.obj_func (Methods.jl:41): affine and increasing in γout[1] at every reference call site (x -> x[1]); any
+    such function has the same minimiser, so it is evaluated on the solution rather than handed to the solver."""
+    f = getattr(query, "obj_func", None)
+    if f is not None and isinstance(query, ReachQuery):
+        if not f(np.array([1.0])) > f(np.array([0.0])):
+            raise ValueError("obj_func must be increasing in γout[1]")
+        soln.objective_value = float(f(soln.values["γout"]))
+    return soln
+
+
 def runQuery(query, opts: AdmmSdpOptions) -> QuerySolution:
     """Methods.runQuery(query, opts) with opts::AdmmSdpOptions (src/Methods/Methods.jl:91-131)."""
     lib = _lib.load()
@@ -337,7 +353,7 @@ def runQuery(query, opts: AdmmSdpOptions) -> QuerySolution:
     o = opts.to_c()
     r, bufs = _alloc_result(cp)
     _lib.check(lib.nnsdp_solve(C.byref(cp.p), C.byref(o), C.byref(r)))
-    soln = _solution(cp, r, bufs)
+    soln = _apply_obj_func(query, _solution(cp, r, bufs))
     if opts.verbose:
         print(f"setup: {soln.setup_time:.3f} \tsolve: {soln.solve_time:.3f} \ttotal: {soln.total_time:.3f} \t"
               f"obj: {soln.objective_value:.5f} ({soln.termination_status}) \tλmax: {r.lambda_max:.7f}")
@@ -352,6 +368,7 @@ class Solver:
 
     def __init__(self, query, opts: AdmmSdpOptions):
         self.lib = _lib.load()
+        self.query = query
         self.cp = _CProblem(query)
         self.o = opts.to_c()
         self.h = C.c_void_p()
@@ -385,12 +402,12 @@ class Solver:
     def run(self) -> QuerySolution:
         r, bufs = _alloc_result(self.cp)
         _lib.check(self.lib.nnsdp_solver_run(self.h, C.byref(r)))
-        return _solution(self.cp, r, bufs)
+        return _apply_obj_func(self.query, _solution(self.cp, r, bufs))
 
     def finish(self) -> QuerySolution:
         r, bufs = _alloc_result(self.cp)
         _lib.check(self.lib.nnsdp_solver_finish(self.h, C.byref(r)))
-        return _solution(self.cp, r, bufs)
+        return _apply_obj_func(self.query, _solution(self.cp, r, bufs))
 
     def close(self):
         if self.h:
@@ -454,7 +471,7 @@ class SolverBatch:
         for s, code in zip(self.solvers, st):
             r, bufs = _alloc_result(s.cp)
             _lib.check(self.lib.nnsdp_solver_finish_status(s.h, int(code), C.byref(r)))
-            out.append(_solution(s.cp, r, bufs))
+            out.append(_apply_obj_func(s.query, _solution(s.cp, r, bufs)))
         return out
 
     def residuals(self):

@@ -165,7 +165,10 @@ class Congruence:
         return np.asarray(oi, dtype=np.int64), np.asarray(ov)
 
 
-def make_congruence(q: Query, eliminate: bool = True, identity: bool = False) -> Congruence:
+INTERVAL_GUARD = 5e-5   # relative floor on the half-width of a neuron's interval (nnsdp_options.interval_guard)
+
+
+def make_congruence(q: Query, eliminate: bool = True, identity: bool = False, guard: float = INTERVAL_GUARD) -> Congruence:
     Zdim = q.net.Zdim
     if identity:
         return Congruence(m=np.zeros(Zdim - 1), h=np.ones(Zdim - 1),
@@ -176,6 +179,13 @@ def make_congruence(q: Query, eliminate: bool = True, identity: bool = False) ->
     assert len(lo) == Zdim - 1
     m = 0.5 * (lo + hi)
     h = 0.5 * (hi - lo)
+    # interval guard: a neuron interval narrower than `guard` x |midpoint| is widened to that (the solver then
+    # works with the weaker, still valid, QC; a gamma feasible for the widened LMI is feasible for the original
+    # one: Z_orig(gamma) = Z_wid(gamma) - 2 gac1 (h_wid^2 - h^2) e_a e_a').  The reference's float32 CROWN boxes
+    # of collapsed deep nets (W10-D80, W20-D70, ...) are narrower than their own rounding error and exclude the
+    # float64 trajectories by up to 2e-5 relative; taken literally they make the QC set empty and rho = 0 "optimal".
+    nin = len(q.qc_input.x1min)
+    h[nin:] = np.maximum(h[nin:], guard * np.abs(m[nin:]))
     if not eliminate:
         # no elimination (e.g. safety queries, where every multiplier has a cost): floor h
         h = np.maximum(h, 1e-6 * max(1.0, float(np.max(h))))
@@ -204,12 +214,20 @@ def build_operator(q: Query, mode: str = "single", normalize: bool = False) -> L
 
     def ev(i):
         return cg.tvec([i], one)
+    def add_box(g, i, l, u):
+        """-2 (z_i - l)(z_i - u); in solver coordinates exactly -2 h^2 (zhat_i^2 - zhat_a^2) (factored: no cancellation)."""
+        if not normalize:
+            coo.add_sym(g, *ev(i), *ev(i), -1.0)             # -2 e_i e_i'
+            coo.add_sym(g, *ev(i), *ea, (l + u))
+            coo.add_sym(g, *ea, *ea, -l * u)                 # -2 l u e_a e_a'
+        elif cg.newpos[i] >= 0:
+            hh = cg.h[i] * cg.h[i]
+            ri, ra = [int(cg.newpos[i])], [cg.nred - 1]
+            coo.add_sym(g, ri, one, ri, one, -hh)
+            coo.add_sym(g, ra, one, ra, one, hh)
     # --- gin
     for i in range(nin):
-        l, u = q.qc_input.x1min[i], q.qc_input.x1max[i]
-        coo.add_sym(i, *ev(i), *ev(i), -1.0)                 # -2 e_i e_i'
-        coo.add_sym(i, *ev(i), *ea, (l + u))
-        coo.add_sym(i, *ea, *ea, -l * u)                     # -2 l u e_a e_a'
+        add_box(i, i, q.qc_input.x1min[i], q.qc_input.x1max[i])
     # --- gout
     if nout:
         cout = 2.0 if isinstance(q.qc_out, QcReachHplane) else 1.0
@@ -228,11 +246,7 @@ def build_operator(q: Query, mode: str = "single", normalize: bool = False) -> L
     ut = [cg.tvec(ui, uv) for (ui, uv, _, _) in rows]
     yt = [ev(y) for (_, _, y, _) in rows]
     for t in range(acdim):
-        l, u = q.qc_bounded.acymin[t], q.qc_bounded.acymax[t]
-        g = o1 + t
-        coo.add_sym(g, *yt[t], *yt[t], -1.0)
-        coo.add_sym(g, *yt[t], *ea, (l + u))
-        coo.add_sym(g, *ea, *ea, -l * u)
+        add_box(o1 + t, rows[t][2], q.qc_bounded.acymin[t], q.qc_bounded.acymax[t])
         g = ol + t
         coo.add_sym(g, *ut[t], *ut[t], -smin[t] * smax[t])   # -2 smin smax u u'
         coo.add_sym(g, *ut[t], *yt[t], smin[t] + smax[t])

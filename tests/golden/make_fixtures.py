@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import nnet_io, qc, operator as op  # noqa: E402
 
-NETS = ["W10-D5", "W10-D10", "W10-D20", "W10-D30", "W10-D50", "W10-D60", "W20-D10", "W20-D20", "W20-D30", "W20-D50",
+NETS = ["W10-D5", "W10-D10", "W10-D20", "W10-D30", "W10-D50", "W10-D60", "W10-D70", "W10-D80",
+        "W20-D10", "W20-D20", "W20-D30", "W20-D40", "W20-D50", "W20-D60", "W20-D70", "W20-D80", "W20-D90", "W20-D100",
         "W40-D20", "W40-D40"]
 PROBLEMS = [("W10-D5", 0), ("W10-D5", 3), ("W10-D10", 0), ("W10-D10", 2), ("W10-D20", 0), ("W20-D10", 0),
             ("W40-D20", 0), ("W40-D20", 2), ("W40-D40", 0)]
@@ -48,14 +49,19 @@ def save_problem(path, q: qc.Query):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--missing-nets-only", action="store_true", help="only add nets/<name>.npz files that do not exist yet")
     args = ap.parse_args()
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(os.path.join(gold, "nets"), exist_ok=True)
     nets = {}
     for name in NETS:
         net = nnet_io.read_nnet(os.path.join(args.ref, "bench", "rand", f"scale-I2-O2-{name}.nnet"))
-        nnet_io.save_npz(net, os.path.join(gold, "nets", f"scale-I2-O2-{name}.npz"))
+        dst = os.path.join(gold, "nets", f"scale-I2-O2-{name}.npz")
+        if not (args.missing_nets_only and os.path.exists(dst)):
+            nnet_io.save_npz(net, dst)
         nets[name] = net
+    if args.missing_nets_only:
+        return
     # published results
     rows = []
     for f in sorted(glob.glob(os.path.join(args.ref, "dump", "scale", "*.csv"))):

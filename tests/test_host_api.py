@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nnsdp_version() == 100
+    m = re.search(r"#define NNSDP_VERSION (\d+)", hdr)
+    assert lib.nnsdp_version() == int(m.group(1))
 
 
 def test_struct_layout_matches_header_field_count():
