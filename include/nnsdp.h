@@ -37,6 +37,8 @@ enum { NNSDP_OUT_SAFETY_S = 0, NNSDP_OUT_HPLANE = 1, NNSDP_OUT_CIRCLE = 2, NNSDP
  * ChordalSdpOptions.decomp_mode = SingleDecomp / DoubleDecomp (src/Methods/chordal_sdp.jl:4-16) */
 enum { NNSDP_DECOMP_DENSE = 0, NNSDP_DECOMP_SINGLE = 1, NNSDP_DECOMP_DOUBLE = 2,
        NNSDP_DECOMP_PATH = 3 /* extension: cliques {x_k, x_k+1, affine}, exact when the output QC has S12 = 0 */ };
+/* ffnet.activ: ReluActiv / TanhActiv (src/MyNeuralNetwork/MyNeuralNetwork.jl:7-9) */
+enum { NNSDP_ACTIV_RELU = 0, NNSDP_ACTIV_TANH = 1 };
 /* termination status; strings as consumed by experiments/acas.jl:77 via nnsdp_status_string() */
 enum { NNSDP_STATUS_OPTIMAL = 0, NNSDP_STATUS_ITERATION_LIMIT = 1, NNSDP_STATUS_TIME_LIMIT = 2,
        NNSDP_STATUS_SLOW_PROGRESS = 3, NNSDP_STATUS_NUMERICAL_ERROR = 4 };
@@ -63,6 +65,8 @@ typedef struct nnsdp_problem {
   const double* yc;       /* CIRCLE / ELLIPSOID: xdims[K] */
   const double* invP;     /* ELLIPSOID: xdims[K] x xdims[K] column-major */
   const double* S;        /* SAFETY_S: (xdims[0]+xdims[K]+1)^2 column-major */
+  int32_t activ;          /* NNSDP_ACTIV_*: ffnet.activ.  TANH: QcActivSector.vardim = lambda_dim, no eta / nu multipliers
+                             (src/Qc/activ_sector.jl:19,49-57); smin/smax are then real numbers in [0,1] (:74-86) */
 } nnsdp_problem;
 
 /* The fields of `AdmmSdpOptions <: QueryOptions` (the replacement of ChordalSdpOptions). */
@@ -95,7 +99,7 @@ typedef struct nnsdp_options {
 /* Contents of Methods.QuerySolution (src/Methods/Methods.jl:46-55) plus solver diagnostics.
  * gamma_* and Z are caller-allocated (any may be NULL to skip).  Sizes:
  *   gamma_in xdims[0]; gamma_out 1 (reach only); gamma_ac1 acdim;
- *   gamma_ac2 lambda_dim + 2*acdim, lambda_dim = (beta+1)*acdim - beta*(beta+1)/2;
+ *   gamma_ac2 lambda_dim + 2*acdim (ReLU) or lambda_dim (Tanh), lambda_dim = (beta+1)*acdim - beta*(beta+1)/2;
  *   Z Zdim x Zdim column-major, Zdim = sum(xdims[0..K-1]) + 1  (values[:Z], Methods.jl:86). */
 typedef struct nnsdp_result {
   double* gamma_in;

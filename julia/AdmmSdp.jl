@@ -39,6 +39,7 @@ struct CProblem
   acymin::Ptr{Float64}; acymax::Ptr{Float64}; smin::Ptr{Float64}; smax::Ptr{Float64}
   beta::Int32; query_kind::Int32; out_kind::Int32
   normal::Ptr{Float64}; yc::Ptr{Float64}; invP::Ptr{Float64}; S::Ptr{Float64}
+  activ::Int32
 end
 struct COptions
   decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
@@ -92,7 +93,8 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin
     p(v) = isempty(v) ? Ptr{Float64}(C_NULL) : pointer(v)
     prob = CProblem(ffnet.K, pointer(xdims), pointer(M), pointer(x1min), pointer(x1max), pointer(acymin), pointer(acymax),
-                    pointer(smin), pointer(smax), Int32(qs.β), qkind, okind, p(normal), p(yc), p(invP), p(S))
+                    pointer(smin), pointer(smax), Int32(qs.β), qkind, okind, p(normal), p(yc), p(invP), p(S),
+                    ffnet.activ isa TanhActiv ? Int32(1) : Int32(0))
     rc = ccall((:nnsdp_solve, LIBNNSDP), Cint, (Ref{CProblem}, Ref{COptions}, Ref{CResult}), prob, copts, res)
     rc == 0 || error("nnsdp_solve failed ($rc): " * unsafe_string(ccall((:nnsdp_last_error, LIBNNSDP), Cstring, ())))
   end

@@ -875,6 +875,7 @@ struct nnsdp_solver {
     pp.K = P.K; pp.xdims = P.xdims.data(); pp.M = Mpack.data();
     pp.x1min = P.x1min.data(); pp.x1max = P.x1max.data(); pp.acymin = P.acymin.data(); pp.acymax = P.acymax.data();
     pp.smin = P.smin.data(); pp.smax = P.smax.data(); pp.beta = P.beta; pp.query_kind = P.query_kind; pp.out_kind = P.out_kind;
+    pp.activ = P.activ;
     pp.normal = P.normal.empty() ? nullptr : P.normal.data();
     pp.yc = P.yc.empty() ? nullptr : P.yc.data();
     pp.invP = P.invP.empty() ? nullptr : P.invP.data();
@@ -1111,7 +1112,7 @@ int nnsdp_problem_dims(const nnsdp_problem* p, int32_t* Zdim, int32_t* acdim, in
   for (int k = 1; k < p->K; ++k) ac += p->xdims[k];
   int beta = p->beta;
   if (beta < 0 || beta > ac) throw std::invalid_argument("beta out of range");
-  int n2 = (beta + 1) * ac - beta * (beta + 1) / 2 + 2 * ac;
+  int n2 = (beta + 1) * ac - beta * (beta + 1) / 2 + (p->activ == NNSDP_ACTIV_TANH ? 0 : 2 * ac);
   if (Zdim) *Zdim = z;
   if (acdim) *acdim = ac;
   if (nac2) *nac2 = n2;

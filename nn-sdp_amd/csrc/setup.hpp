@@ -30,7 +30,7 @@ struct SpVec {
 
 // deep copy of the caller's problem (the ABI says: copy in, retain nothing of the caller's)
 struct ProblemCopy {
-  int K = 0, beta = 0, query_kind = 0, out_kind = 0;
+  int K = 0, beta = 0, query_kind = 0, out_kind = 0, activ = 0;
   std::vector<int> xdims;
   std::vector<std::vector<double>> W;  // W[k] row-major n_{k+1} x n_k
   std::vector<std::vector<double>> b;  // b[k]
@@ -49,6 +49,8 @@ struct ProblemCopy {
     if (beta < 0) throw std::invalid_argument("beta must be >= 0");
     query_kind = p->query_kind;
     out_kind = p->out_kind;
+    activ = p->activ;
+    if (activ != NNSDP_ACTIV_RELU && activ != NNSDP_ACTIV_TANH) throw std::invalid_argument("unsupported activation (activ_sector.jl:88)");
     offs.assign(K + 1, 0);
     for (int k = 0; k < K; ++k) offs[k + 1] = offs[k] + xdims[k];
     Zdim = offs[K] + 1;
@@ -81,9 +83,16 @@ struct ProblemCopy {
     smax.assign(p->smax, p->smax + acdim);
     for (int i = 0; i < xdims[0]; ++i)
       if (!(x1min[i] <= x1max[i])) throw std::invalid_argument("x1min <= x1max violated");
-    for (int i = 0; i < acdim; ++i) {
+    for (int i = 0; i < acdim; ++i)
       if (!(acymin[i] <= acymax[i])) throw std::invalid_argument("acymin <= acymax violated (activ_bounded.jl:8)");
-      if (!(smin[i] <= smax[i])) throw std::invalid_argument("smin <= smax violated (activ_sector.jl:13)");
+    // `@assert smin <= smax` (activ_sector.jl:13) compares two Julia vectors, i.e. lexicographically: the first entry that
+    // differs decides.  (The tanh branch of makeSectorMinMax returns smin > smax on negative intervals, :76-77; the sector
+    // generator is symmetric in the two slopes, so that is harmless, and it passes the reference's assertion.)
+    for (int i = 0; i < acdim; ++i) {
+      if (smin[i] != smin[i] || smax[i] != smax[i]) throw std::invalid_argument("smin / smax contain NaN");
+      if (smin[i] == smax[i]) continue;
+      if (smin[i] > smax[i]) throw std::invalid_argument("smin <= smax violated (activ_sector.jl:13)");
+      break;
     }
     nin = xdims[0];
     if (query_kind == NNSDP_QUERY_REACH) {
@@ -105,7 +114,7 @@ struct ProblemCopy {
     n1 = acdim;
     // lambda_dim = sum((acdim-beta):acdim) (activ_sector.jl:18) = acdim + #pairs
     npairs = beta * acdim - beta * (beta + 1) / 2;
-    n2 = acdim + npairs + 2 * acdim;
+    n2 = acdim + npairs + (activ == NNSDP_ACTIV_RELU ? 2 * acdim : 0);   // vardim (activ_sector.jl:19)
     ng = nin + nout + n1 + n2;
   }
 };
@@ -322,10 +331,12 @@ class OperatorBuilder {
       add_box(o1 + t, P.nin + t, P.acymin[t], P.acymax[t]);   // activ_bounded.jl:19-21
       add_sym(ol + t, ut[t], ut[t], -sn * sx);             // activ_sector.jl:42 (Q11)
       add_sym(ol + t, ut[t], yt[t], sn + sx);              // activ_sector.jl:43 (Q12)
-      add_sym(oe + t, ut[t], ea, -sn);                     // activ_sector.jl:55
-      add_sym(oe + t, yt[t], ea, 1.0);                     // activ_sector.jl:56
-      add_sym(on + t, ut[t], ea, -sx);
-      add_sym(on + t, yt[t], ea, 1.0);
+      if (P.activ == NNSDP_ACTIV_RELU) {                   // eta, nu exist for ReLU only (activ_sector.jl:49-57)
+        add_sym(oe + t, ut[t], ea, -sn);                   // activ_sector.jl:55
+        add_sym(oe + t, yt[t], ea, 1.0);                   // activ_sector.jl:56
+        add_sym(on + t, ut[t], ea, -sx);
+        add_sym(on + t, yt[t], ea, 1.0);
+      }
     }
     // repeated-nonlinearity pairs, i-major order (activ_sector.jl:29-35)
     int r = 0;

@@ -30,6 +30,7 @@ class Problem(C.Structure):
         ("smin", c_double_p), ("smax", c_double_p),
         ("beta", C.c_int32), ("query_kind", C.c_int32), ("out_kind", C.c_int32),
         ("normal", c_double_p), ("yc", c_double_p), ("invP", c_double_p), ("S", c_double_p),
+        ("activ", C.c_int32),
     ]
 
 

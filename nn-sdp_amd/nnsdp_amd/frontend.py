@@ -41,12 +41,18 @@ def read_nnet(path: str) -> M.FeedFwdNet:
     return M.FeedFwdNet(xdims=sizes, Ms=Ms)
 
 
+def _activ_fn(net: M.FeedFwdNet):
+    """makeActiv (src/MyNeuralNetwork/MyNeuralNetwork.jl:29-37)"""
+    return np.tanh if M._activ_code(net.activ) == M.ACTIV_TANH else (lambda v: np.maximum(v, 0.0))
+
+
 def evalFeedFwdNet(net: M.FeedFwdNet, x) -> np.ndarray:
     xk = np.asarray(x, dtype=np.float64)
     vec = xk.ndim == 1
     xk = xk[:, None] if vec else xk
+    ac = _activ_fn(net)
     for Mk in net.Ms[:-1]:
-        xk = np.maximum(Mk[:, :-1] @ xk + Mk[:, -1:], 0.0)
+        xk = ac(Mk[:, :-1] @ xk + Mk[:, -1:])
     xk = net.Ms[-1][:, :-1] @ xk + net.Ms[-1][:, -1:]
     return xk[:, 0] if vec else xk
 
@@ -63,6 +69,73 @@ def randomNetwork(xdims: Sequence[int], sigma: float = None, seed: int = 1234) -
         sigma = 2.0 / np.sqrt(width * np.log(width)) if width > 1 else 1.0
     rng = np.random.default_rng(seed)
     return M.FeedFwdNet(xdims=xdims, Ms=[rng.normal(0.0, sigma, size=(xdims[k + 1], xdims[k] + 1)) for k in range(len(xdims) - 1)])
+
+
+def loadFromFileScaled(path: str, scaling=None):
+    """loadFromFileScaled (src/MyNeuralNetwork/network_files.jl:84-114): W_k -> alpha_k W_k, b_k -> prod(alpha[1..k]) b_k, so
+    that f'(x) = prod(alpha) f(x) for a ReLU network.  `scaling`: None / "none" (NoScaling), "sqrtlog" (SqrtLogScaling),
+    ("norm", v) (FixedNormScaling(Wk_opnorm = v)), ("const", a) (FixedConstScaling(α = a)).  -> (scaled net, alphas)."""
+    net = read_nnet(path)
+    K = net.K
+    Ws, bs = [Mk[:, :-1] for Mk in net.Ms], [Mk[:, -1] for Mk in net.Ms]
+    opn = lambda W: float(np.linalg.norm(W, 2))
+    if scaling is None or scaling == "none":
+        al = np.ones(K)
+    elif scaling == "sqrtlog":
+        tgt = [np.sqrt(c * np.log(c) / K) for c in (net.xdims[k] + net.xdims[k + 1] for k in range(K))]
+        al = np.array([tgt[k] / opn(Ws[k]) for k in range(K)])
+    elif isinstance(scaling, tuple) and scaling[0] == "norm":
+        al = np.array([float(scaling[1]) / opn(W) for W in Ws])
+    elif isinstance(scaling, tuple) and scaling[0] == "const":
+        al = float(scaling[1]) * np.ones(K)
+    else:
+        raise ValueError(f"unrecognized scaling method: {scaling}")
+    Ms = [np.hstack([al[k] * Ws[k], (np.prod(al[:k + 1]) * bs[k])[:, None]]) for k in range(K)]
+    return M.FeedFwdNet(xdims=list(net.xdims), Ms=Ms), al
+
+
+def intervalsWorstCase(x1min, x1max, net: M.FeedFwdNet):
+    """Intervals.intervalsWorstCase (src/Intervals/intervals_easy.jl:2-37): plain interval arithmetic, ReLU or tanh (both
+    monotone).  -> (x_intvs, acx_intvs) like makeIntervalsInfo."""
+    lo, hi = np.asarray(x1min, dtype=np.float64), np.asarray(x1max, dtype=np.float64)
+    ac = _activ_fn(net)
+    x_intvs, acx = [(lo, hi)], []
+    for k, Mk in enumerate(net.Ms):
+        W, b = Mk[:, :-1], Mk[:, -1]
+        pl = np.maximum(W, 0) @ lo + np.minimum(W, 0) @ hi + b
+        pu = np.maximum(W, 0) @ hi + np.minimum(W, 0) @ lo + b
+        if k < net.K - 1:
+            acx.append((pl, pu))
+            lo, hi = ac(pl), ac(pu)
+        else:
+            lo, hi = pl, pu
+        x_intvs.append((lo, hi))
+    return x_intvs, acx
+
+
+def makeSectorMinMax(acxmin, acxmax, activ=M.ReluActiv):
+    """Qc.makeSectorMinMax (src/Qc/activ_sector.jl:63-90), both activations, same arithmetic (including 0/0 = NaN for a tanh
+    pre-activation bound that is exactly 0, as in the reference)."""
+    acxmin, acxmax = np.asarray(acxmin, dtype=np.float64), np.asarray(acxmax, dtype=np.float64)
+    if len(acxmin) != len(acxmax):
+        raise ValueError("acxmin / acxmax length mismatch")
+    eps = 1e-4
+    code = M._activ_code(activ)
+    if code == M.ACTIV_RELU:
+        return (acxmin > eps).astype(np.float64), 1.0 - (acxmax < -eps).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tlo, thi = np.tanh(acxmin) / acxmin, np.tanh(acxmax) / acxmax
+    same = acxmin * acxmax >= 0
+    return np.where(same, thi, np.minimum(tlo, thi)), np.where(same, tlo, 1.0)
+
+
+def makeQcActivsIntvs(net: M.FeedFwdNet, x_intvs, acx_intvs, beta: int):
+    """Qc.makeQcActivsIntvs (src/Qc/activ.jl:45-66) from given interval information."""
+    acymin = np.concatenate([iv[0] for iv in x_intvs[1:-1]])
+    acymax = np.concatenate([iv[1] for iv in x_intvs[1:-1]])
+    smin, smax = makeSectorMinMax(np.concatenate([iv[0] for iv in acx_intvs]), np.concatenate([iv[1] for iv in acx_intvs]), net.activ)
+    return [M.QcActivBounded(acymin=acymin, acymax=acymax),
+            M.QcActivSector(acxdim=len(acymin), beta=int(beta), smin=smin, smax=smax, activ=net.activ)]
 
 
 # ----------------------------------------------------------------------------- f1: CROWN-sliced intervals
@@ -102,6 +175,9 @@ def makeIntervalsInfo(x1min, x1max, net: M.FeedFwdNet):
 
 def makeQcActivs(net: M.FeedFwdNet, x1min, x1max, beta: int):
     """Qc.makeQcActivs (src/Qc/activ.jl:45-72): bounded + sector QCs from the interval pre-processing."""
+    if M._activ_code(net.activ) != M.ACTIV_RELU:
+        # the native pre-processing restates auto_LiRPA's ReLU relaxation only; tanh networks go through interval arithmetic
+        return makeQcActivsIntvs(net, *intervalsWorstCase(x1min, x1max, net), beta)
     acymin, acymax, _, _, smin, smax, _, _ = _intervals_native(x1min, x1max, net)
     return [M.QcActivBounded(acymin=acymin, acymax=acymax),
             M.QcActivSector(acxdim=len(acymin), beta=int(beta), smin=smin, smax=smax)]

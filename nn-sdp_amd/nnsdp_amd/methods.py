@@ -27,6 +27,24 @@ import numpy as np
 from . import _lib
 
 QUERY_SAFETY, QUERY_REACH = 0, 1
+ACTIV_RELU, ACTIV_TANH = 0, 1
+
+
+class ReluActiv:
+    """MyNeuralNetwork.ReluActiv (src/MyNeuralNetwork/MyNeuralNetwork.jl:8)"""
+    code = ACTIV_RELU
+
+
+class TanhActiv:
+    """MyNeuralNetwork.TanhActiv (src/MyNeuralNetwork/MyNeuralNetwork.jl:9)"""
+    code = ACTIV_TANH
+
+
+def _activ_code(a) -> int:
+    code = getattr(a, "code", a)
+    if code not in (ACTIV_RELU, ACTIV_TANH):
+        raise ValueError(f"unsupported activation: {a}")
+    return int(code)
 OUT_SAFETY_S, OUT_HPLANE, OUT_CIRCLE, OUT_ELLIPSOID = 0, 1, 2, 3
 
 
@@ -59,8 +77,10 @@ def _f64(a) -> np.ndarray:
 class FeedFwdNet:
     xdims: List[int]
     Ms: List[np.ndarray]
+    activ: Any = ReluActiv
 
     def __post_init__(self):
+        _activ_code(self.activ)
         self.xdims = [int(v) for v in self.xdims]
         self.Ms = [_f64(M) for M in self.Ms]
         assert len(self.xdims) >= 3
@@ -145,12 +165,15 @@ class QcActivSector:
     beta: int
     smin: np.ndarray
     smax: np.ndarray
+    activ: Any = ReluActiv
 
     def __post_init__(self):
+        _activ_code(self.activ)
         self.smin, self.smax = _f64(self.smin), _f64(self.smax)
         assert self.acxdim == len(self.smin) == len(self.smax)
         assert 0 <= self.beta
-        assert np.all(self.smin <= self.smax)
+        # `@assert smin <= smax` (activ_sector.jl:13) is Julia's lexicographic vector comparison
+        assert self.smin.tolist() <= self.smax.tolist()
 
     @property
     def lamdim(self) -> int:
@@ -158,7 +181,8 @@ class QcActivSector:
 
     @property
     def vardim(self) -> int:
-        return self.lamdim + 2 * self.acxdim
+        # (activ isa ReluActiv) ? _λdim + 2 * acxdim : _λdim   (activ_sector.jl:19)
+        return self.lamdim + (2 * self.acxdim if _activ_code(self.activ) == ACTIV_RELU else 0)
 
 
 @dataclass
@@ -259,6 +283,9 @@ class _CProblem:
         p.acymin, p.acymax = self._ptr(qb.acymin), self._ptr(qb.acymax)
         p.smin, p.smax = self._ptr(qs.smin), self._ptr(qs.smax)
         p.beta = int(qs.beta)
+        if _activ_code(qs.activ) != _activ_code(net.activ):
+            raise ValueError("QcActivSector.activ does not match ffnet.activ")
+        p.activ = _activ_code(net.activ)
         m = net.xdims[-1]
         if isinstance(query, ReachQuery):
             p.query_kind = QUERY_REACH

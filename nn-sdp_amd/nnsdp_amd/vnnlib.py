@@ -176,15 +176,39 @@ def hplaneS(normal, h: float, net: M.FeedFwdNet) -> np.ndarray:
     return S
 
 
-def loadVnnlibCnf(spec, net: M.FeedFwdNet):
-    """CNF of (QcInputBox, QcSafety): one disjunctive clause per unsafe polytope, one literal per row."""
+def scaleS(S, alphas, net: M.FeedFwdNet) -> np.ndarray:
+    """Qc.scaleS (src/Qc/output.jl:109-124): the safety matrix for a network whose weights were scaled by alphas
+    (loadFromFileScaled), y' = prod(alphas) y: the blocks that touch y are divided by alpha (once per factor of y)."""
+    alphas = np.asarray(alphas, dtype=np.float64)
+    if len(alphas) != net.K:
+        raise ValueError("one alpha per layer")
+    a = float(np.prod(alphas))
+    d1, dK = net.xdims[0], net.xdims[-1]
+    S = np.asarray(S, dtype=np.float64)
+    if S.shape != (d1 + dK + 1, d1 + dK + 1):
+        raise ValueError("S must be (xdims[1] + xdims[end] + 1) square")
+    D = np.concatenate([np.ones(d1), np.full(dK, 1.0 / a), [1.0]])
+    out = S * D[:, None] * D[None, :]
+    # the reference rebuilds the lower blocks from the upper ones (S12', S13', S23'): the result is symmetric by construction
+    iu = np.triu_indices(len(D), 1)
+    out[(iu[1], iu[0])] = out[iu]
+    return out
+
+
+def loadVnnlibCnf(spec, net: M.FeedFwdNet, alphas=None):
+    """CNF of (QcInputBox, QcSafety): one disjunctive clause per unsafe polytope, one literal per row.  `alphas`: the
+    scaling factors of loadFromFileScaled, applied through scaleS as experiments/vnnlib_utils.jl:45-47 does."""
     cnf = []
     for (lo, hi), specs in read_vnnlib(spec, net.xdims[0], net.xdims[-1]):
         qin = M.QcInputBox(x1min=lo, x1max=hi)
         for A, b in specs:
             if len(b) == 0:
                 raise ValueError("vnnlib: a case without output constraints is trivially violated")
-            cnf.append([(qin, M.QcSafety(S=hplaneS(-A[i], -b[i] - SPEC_EPS, net))) for i in range(len(b))])
+            lits = []
+            for i in range(len(b)):
+                S = hplaneS(-A[i], -b[i] - SPEC_EPS, net)
+                lits.append((qin, M.QcSafety(S=scaleS(S, alphas, net) if alphas is not None else S)))
+            cnf.append(lits)
     return cnf
 
 
@@ -206,14 +230,18 @@ def loadReluQueriesCnf(net: M.FeedFwdNet, spec, beta: int):
 
 
 def isSolutionGood(soln: M.QuerySolution) -> bool:
-    """experiments/acas.jl:76-79"""
-    if soln.termination_status == "OPTIMAL":
-        return True
+    """experiments/acas.jl:71-79 accepts status == "OPTIMAL" OR eigmax(Z) <= NSD_TOL.  There OPTIMAL is MOSEK's
+    interior-point certificate; here it only says that the ADMM residuals are small in the solver's coordinates, which does
+    not bound eigmax(Z) in the reference's.  So the certificate itself is always checked: multipliers >= 0 and
+    eigmax(Z(gamma)) <= NSD_TOL, whatever the status (NUMERICAL_ERROR excepted: never good)."""
+    if soln.termination_status == "NUMERICAL_ERROR":
+        return False
     lam = soln.summary.get("lambda_max") if soln.summary else None
     if lam is None:
         Z = np.asarray(soln.values["Z"])
         lam = float(np.linalg.eigvalsh(0.5 * (Z + Z.T))[-1])
-    return bool(np.isfinite(lam) and lam <= NSD_TOL)
+    gmin = min((float(np.min(soln.values[k])) for k in ("γin", "γout", "γac1", "γac2") if k in soln.values and len(soln.values[k])), default=0.0)
+    return bool(np.isfinite(lam) and lam <= NSD_TOL and gmin >= 0.0)
 
 
 def reachForm(query: M.SafetyQuery, ybounds=None):
@@ -253,8 +281,9 @@ def safetyFromReach(soln: M.QuerySolution, h: float, h0: float = 0.0) -> M.Query
     Z = np.array(soln.values["Z"], dtype=np.float64, copy=True)
     Z[-1, -1] -= 2.0 * (h - rho)
     lam = float(np.linalg.eigvalsh(0.5 * (Z + Z.T))[-1])
-    ok = bool(np.isfinite(lam) and lam <= NSD_TOL)
     vals = {k: v for k, v in soln.values.items() if k != "γout"}
+    gmin = min((float(np.min(vals[k])) for k in ("γin", "γac1", "γac2") if len(vals[k])), default=0.0)
+    ok = bool(np.isfinite(lam) and lam <= NSD_TOL and gmin >= 0.0 and rho <= h)
     vals["Z"] = Z
     summ = dict(soln.summary)
     summ.update(lambda_max=lam, reach_bound=rho, offset=h, margin=h - rho, reach_status=soln.termination_status)

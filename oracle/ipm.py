@@ -205,6 +205,8 @@ def solve_lmi(Z0: np.ndarray, G: np.ndarray, c: np.ndarray, opts: Optional[IpmOp
         Ss = 0.5 * (Ss + Ss.T)
     if status != "OPTIMAL" and best is not None:
         _, y, Xs, _ = best
+        if best[0] <= 1e-7:
+            status = "NEAR_OPTIMAL"      # stalled (step length / Cholesky) inside 1e-7 of optimality: these models have no Slater point
     gamma = np.zeros(ng_full)
     gamma[keep] = np.maximum(y, 0.0)
     Z = Z0 + np.tensordot(gamma, G, axes=1)

@@ -241,7 +241,8 @@ def build_operator(q: Query, mode: str = "single", normalize: bool = False) -> L
     ov = ol + acdim                  # pair multipliers
     oe = ov + len(pairs)             # eta
     on = oe + acdim                  # nu
-    assert on + acdim == ng
+    relu = q.qc_sector.activ == "relu"
+    assert (on + acdim if relu else oe) == ng
     smin, smax = q.qc_sector.smin, q.qc_sector.smax
     ut = [cg.tvec(ui, uv) for (ui, uv, _, _) in rows]
     yt = [ev(y) for (_, _, y, _) in rows]
@@ -250,12 +251,13 @@ def build_operator(q: Query, mode: str = "single", normalize: bool = False) -> L
         g = ol + t
         coo.add_sym(g, *ut[t], *ut[t], -smin[t] * smax[t])   # -2 smin smax u u'
         coo.add_sym(g, *ut[t], *yt[t], smin[t] + smax[t])
-        g = oe + t
-        coo.add_sym(g, *ut[t], *ea, -smin[t])
-        coo.add_sym(g, *yt[t], *ea, 1.0)
-        g = on + t
-        coo.add_sym(g, *ut[t], *ea, -smax[t])
-        coo.add_sym(g, *yt[t], *ea, 1.0)
+        if relu:
+            g = oe + t
+            coo.add_sym(g, *ut[t], *ea, -smin[t])
+            coo.add_sym(g, *yt[t], *ea, 1.0)
+            g = on + t
+            coo.add_sym(g, *ut[t], *ea, -smax[t])
+            coo.add_sym(g, *yt[t], *ea, 1.0)
     for r, (i, j) in enumerate(pairs):
         g = ov + r
         dyi = np.concatenate([yt[i][0], yt[j][0]]); dyv = np.concatenate([yt[i][1], -yt[j][1]])

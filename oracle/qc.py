@@ -113,6 +113,7 @@ class QcActivSector:
     smax: np.ndarray
     base_smin: float = 0.0
     base_smax: float = 1.0
+    activ: str = "relu"            # "relu" | "tanh"  (ReluActiv / TanhActiv)
 
     @property
     def lamdim(self) -> int:
@@ -121,7 +122,8 @@ class QcActivSector:
 
     @property
     def vardim(self) -> int:
-        return self.lamdim + 2 * self.acxdim      # ReLU: lambda, eta, nu
+        # (activ isa ReluActiv) ? _λdim + 2 * acxdim : _λdim   (activ_sector.jl:19)
+        return self.lamdim + (2 * self.acxdim if self.activ == "relu" else 0)
 
     def pairs(self) -> List[Tuple[int, int]]:
         # ijs = [(i, j) for i in 1:(acxdim-1) for j in (i+1):acxdim if j-i <= beta]
@@ -254,10 +256,13 @@ def make_Q_sector(gac, qc: QcActivSector) -> np.ndarray:
     Q12 = np.diag((smin + smax) * lam0) + (bmin + bmax) * T
     Q22 = -2.0 * T
     ld = qc.lamdim
-    eta = gac[ld:ld + n]
-    nu = gac[ld + n:ld + 2 * n]
-    Q13 = -smin * eta - smax * nu
-    Q23 = eta + nu
+    Q13 = np.zeros(n)
+    Q23 = np.zeros(n)
+    if qc.activ == "relu":            # activ_sector.jl:49-57
+        eta = gac[ld:ld + n]
+        nu = gac[ld + n:ld + 2 * n]
+        Q13 = -smin * eta - smax * nu
+        Q23 = eta + nu
     Q = np.zeros((2 * n + 1, 2 * n + 1))
     Q[:n, :n] = Q11
     Q[:n, n:2 * n] = Q12
@@ -288,13 +293,47 @@ def make_Zac(gac, qc, net: FeedFwdNet, R: Optional[np.ndarray] = None) -> np.nda
     return R.T @ Q @ R
 
 
-def make_sector_min_max(acxmin, acxmax) -> Tuple[np.ndarray, np.ndarray]:
+def make_sector_min_max(acxmin, acxmax, activ: str = "relu") -> Tuple[np.ndarray, np.ndarray]:
+    """makeSectorMinMax (src/Qc/activ_sector.jl:63-90), both branches, statement by statement."""
+    acxmin = np.asarray(acxmin, dtype=np.float64)
+    acxmax = np.asarray(acxmax, dtype=np.float64)
+    assert len(acxmin) == len(acxmax)
     eps = 1e-4
-    smin = np.zeros(len(acxmin))
-    smax = np.ones(len(acxmax))
-    smin[np.asarray(acxmin) > eps] = 1.0
-    smax[np.asarray(acxmax) < -eps] = 0.0
-    return smin, smax
+    if activ == "relu":
+        smin = np.zeros(len(acxmin))
+        smax = np.ones(len(acxmax))
+        smin[acxmin > eps] = 1.0
+        smax[acxmax < -eps] = 0.0
+        return smin, smax
+    if activ == "tanh":
+        smin = np.zeros(len(acxmin))
+        smax = np.ones(len(acxmax))
+        for i in range(len(acxmin)):
+            if acxmin[i] * acxmax[i] >= 0:
+                smin[i] = np.tanh(acxmax[i]) / acxmax[i]
+                smax[i] = np.tanh(acxmin[i]) / acxmin[i]
+            else:
+                smin[i] = min(np.tanh(acxmin[i]) / acxmin[i], np.tanh(acxmax[i]) / acxmax[i])
+                smax[i] = 1.0
+        return smin, smax
+    raise ValueError(f"unsupported activation: {activ}")
+
+
+def scale_S(S, alphas, net: FeedFwdNet) -> np.ndarray:
+    """scaleS (src/Qc/output.jl:109-124): S for the scaled network f' = prod(alphas) f, block by block through the
+    selectors F_i = E(i, [xdims[1]; xdims[end]; 1])."""
+    assert len(alphas) == net.K
+    alpha = float(np.prod(alphas))
+    sdims = [net.xdims[0], net.xdims[-1], 1]
+    F1, F2, F3 = E(0, sdims), E(1, sdims), E(2, sdims)
+    S = np.asarray(S, dtype=np.float64)
+    S11 = F1 @ S @ F1.T
+    S12 = F1 @ S @ F2.T / alpha
+    S13 = F1 @ S @ F3.T
+    S22 = F2 @ S @ F2.T / alpha ** 2
+    S23 = F2 @ S @ F3.T / alpha
+    S33 = F3 @ S @ F3.T
+    return np.block([[S11, S12, S13], [S12.T, S22, S23], [S13.T, S23.T, S33]])
 
 
 def make_qc_activs(net: FeedFwdNet, x1min, x1max, beta: int,

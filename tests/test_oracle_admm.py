@@ -34,24 +34,26 @@ def test_admm_converges_w10_d5():
     assert abs(rd_.objective - r.objective) <= 2e-4 * abs(r.objective)
 
 
-# (net, beta, iterations, relative tolerance vs the published values, note)
+# (net, beta, iterations): ONE tolerance, 1e-3 relative to the nearest published value
 PUBLISHED = [
-    ("W10-D10", 0, 5000, 1e-3),
-    ("W10-D20", 0, 6000, 2e-3),
+    ("W10-D10", 0, 5000),
+    ("W10-D20", 0, 12000),
 ]
 
 
-@pytest.mark.parametrize("name,beta,iters,tol", PUBLISHED)
-def test_oracle_vs_published_rho(name, beta, iters, tol):
+@pytest.mark.parametrize("name,beta,iters", PUBLISHED)
+def test_oracle_vs_published_rho(name, beta, iters):
     """dump/scale/*.csv obj_val of the OPTIMAL rows; P and yc of the reference came from Julia's RNG
-    (Utils/qc.jl:43), so 1e-3 relative is the parity tolerance.  W10-D20 sits at
-    1.2e-3 and W20-D10 at 1.0e-2 below the published values (see DESIGN.md 'Parity status')."""
+    (Utils/qc.jl:43), so 1e-3 relative is the parity tolerance.  The rows whose published value is
+    further than that from the optimum of the LMI are listed, with the cause, in tests/test_published_parity.py and
+    DESIGN.md section 7 (W20-D10 is too slow for this numpy solver inside the CPU suite)."""
     pub = helpers.published_rho(name, beta)
     assert len(pub) == 3
     q = helpers.oracle_query(helpers.load_problem(name, beta))
-    r = oadmm.admm_solve(oop.build_operator(q, "single", normalize=True), oadmm.AdmmOptions(max_iters=iters))
+    r = oadmm.admm_solve(oop.build_operator(q, "double", normalize=True), oadmm.AdmmOptions(max_iters=iters))
     rel = min(abs(r.objective - p) / abs(p) for p in pub)
-    assert rel <= tol, (r.objective, pub, rel)
+    assert rel <= 1e-3, (r.objective, pub, rel)
+    assert r.objective <= min(pub)          # below every published value: those are inexact interior-point iterates
 
 
 def test_dump_table_fixture():
