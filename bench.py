@@ -8,8 +8,13 @@ torch.distributed.run, one rank per GPU.  One JSON line on rank 0.
              whole SDP, all data resident in HBM before the timed region.
   * N = 1  : workload = BASELINE.json configs[2], "bench/rand W=40 D=20, full chordal decomposition,
              all cliques batched on 1 x MI355X" (fixture tests/golden/problem_W40-D20_b0.npz).
-  * N > 1  : weak scaling over INDEPENDENT SDPs (one per rank, no data-path collective); value is the
-             aggregate iterations/s.  See DESIGN.md "Multi-GPU".
+  * N > 1  : `value` = the north star's clique-sharded figure: ONE W40-D20 SDP, its PSD blocks sharded over the N GPUs
+             (contiguous ranges balanced by n_k^3), one RCCL all-reduce of the consensus sum per iteration ("strong"
+             scaling).  The replica figure - N independent SDPs, one per GPU, no data-path collective ("weak") - is
+             measured in the same run and reported beside it under "replicas".  torch.distributed (gloo) only launches,
+             synchronises and takes the max over ranks; the data-path collective is the library's own ncclAllReduce.
+             If the sharded leg cannot start (RCCL unavailable), `value` falls back to the replica figure and says so.
+             See DESIGN.md "Multi-GPU".
   * roofline: the projection kernel is compute bound (fp64), so `bound` = "mfma" with the fp64
              vector/matrix peak; achieved = algorithmic flops (10 * sum n_k^3 of the blocks solved)
              / average kernel duration from HIP events recorded on the solver's stream inside the
@@ -81,9 +86,9 @@ def main():
     ap.add_argument("--beta", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
-                    help="N > 1: replica = one independent SDP per GPU, no data-path collective (weak scaling, default); "
-                         "shard = ONE SDP, cliques sharded over the GPUs, RCCL all-reduce of the consensus sum per iteration (strong)")
+    ap.add_argument("--mode", choices=["auto", "replica", "shard"], default="auto",
+                    help="N > 1: auto/shard = ONE SDP, cliques sharded over the GPUs, RCCL all-reduce of the consensus sum per iteration "
+                         "(strong; the replica figure is reported beside it); replica = one independent SDP per GPU only (weak)")
     ap.add_argument("--batch", type=int, default=13, help="independent SDPs solved side by side in the batched leg (0/1 = skip)")
     ap.add_argument("--cert-seconds", type=float, default=30.0, help="time cap of the time-to-certificate solve (0 = skip)")
     args = ap.parse_args()
@@ -94,29 +99,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if os.environ.get("NNSDP_BENCH_ONE_DEVICE"):    # rehearsal of the N > 1 control flow on a one-GPU box (all ranks on device 0)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        # control plane only (launch, barrier, max over ranks, the 128-byte RCCL id): gloo, so that the one RCCL
+        # communicator on the GPUs is the library's own
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     import helpers
     import nnsdp_amd as na
     d = helpers.load_problem(args.workload, args.beta)
     q = helpers.product_query(d)
     opts = na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9, device=local_rank)
-    solver = na.Solver(q, opts)           # setup: pattern, generators, factorisation; everything now in HBM
-    shard = args.mode == "shard"
-    if shard:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(na.comm_unique_id()), dtype=torch.uint8).cuda()
-        if dist is not None:
-            dist.broadcast(uid, src=0)
-        solver.set_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
-    if args.burn_in > 0:
-        solver.advance(args.burn_in)      # regular solve loop (checks, sigma / tolerance adaptation), no stopping
-    solver.iterate(args.warmup, time_eig=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -124,15 +121,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    eig_ms = solver.iterate(args.steps, time_eig=True)   # eager launches + HIP events around the projection kernel
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    def all_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    def timed_leg(solver):
+        """burn-in + W warmup + exactly K timed iterations (barrier + synchronize on both sides, MAX over ranks)"""
+        if args.burn_in > 0:
+            solver.advance(args.burn_in)      # regular solve loop (checks, sigma / tolerance adaptation), no stopping
+        solver.iterate(args.warmup, time_eig=True)
+        barrier()
+        t0 = time.perf_counter()
+        eig_ms = solver.iterate(args.steps, time_eig=True)   # eager launches + HIP events around the projection kernel
+        barrier()
+        return all_max(time.perf_counter() - t0), eig_ms
+
+    shard = world > 1 and args.mode in ("auto", "shard")
+    shard_error = None
+    replicas = None
+    if world > 1:
+        # replica leg: one independent SDP per GPU, no data-path collective
+        rs = na.Solver(q, opts)
+        dt_r, _ = timed_leg(rs)
+        rs.close()
+        replicas = {"value": world * args.steps / dt_r, "unit": "ADMM iters/s", "scaling": "weak", "ms_per_step": 1e3 * dt_r / args.steps,
+                    "note": f"{world} independent W40-D20 SDPs, one per GPU, no data-path collective"}
+    solver = na.Solver(q, opts)           # setup: pattern, generators, factorisation; everything now in HBM
+    if shard:
+        ok = 1.0
+        try:
+            ub = [na.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ub, src=0)
+            solver.set_comm(world, rank, ub[0])
+        except Exception as e:      # RCCL missing / communicator failure: report, fall back to the replica figure
+            shard_error = repr(e)
+            ok = 0.0
+        if all_max(1.0 - ok) > 0.0:
+            shard = False
+            shard_error = shard_error or "another rank failed to join the RCCL communicator"
+            solver.close()
+            solver = na.Solver(q, opts)
+    dt, eig_ms = timed_leg(solver)
     pres, dres, pobj, dobj = solver.residuals()
     soln = solver.finish()
     sm = soln.summary
@@ -162,12 +194,13 @@ def main():
         ach_tf = flops / eig_avg_s / 1e12
         out = {
             "metric": "ADMM iters/sec + wall-clock to eps-cert, bench/rand W=40 D=20",
-            "value": (1 if shard else world) * args.steps / dt,
+            "value": (1 if shard or world == 1 else world) * args.steps / dt,
             "unit": "ADMM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "burn_in_iters": args.burn_in,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
             "scaling": "strong" if shard else "weak",
+            "replicas": replicas, "shard_error": shard_error,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "reference bench/rand random network (fixture), CROWN-sliced intervals and sampled ellipsoid precomputed on the host",

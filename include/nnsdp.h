@@ -211,8 +211,16 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
  * (balanced by n_k^3); the consensus sum sum_k H_k'(2 w_k - nu_k) is exchanged with ONE ncclAllReduce (RCCL
  * over xGMI) per iteration, everything else is replicated.  The 128-byte unique id is produced on rank 0
  * and distributed by the host launcher (torch.distributed in bench.py --mode shard).  RCCL is dlopen'ed on
- * first use.  Independent SDPs need none of this (bench.py default, nnsdp_amd/parallel.py). */
+ * first use.  Independent SDPs need none of this (nnsdp_amd/parallel.py).  Every stopping / penalty / tolerance decision of
+ * a sharded solve is taken from all-reduced numbers, so all ranks take it identically (including the time limit).
+ * EXPERIMENTAL until a multi-rank run on hardware is on record (the build pool offers one GPU): covered by a one-rank
+ * RCCL test on the GPU and a world-2 gloo test of the same partition and arithmetic. */
 int nnsdp_comm_unique_id(char* id128);
+/* Host-only (no GPU, no RCCL): the PSD blocks the solver works on for (problem, options) and their partition over `nranks`
+ * ranks - exactly what nnsdp_solver_set_comm uses.  Two-pass: n_blocks first (block_n = start = NULL), then
+ * block_n[n_blocks] (block dimensions after the normalisation) and start[nranks+1] (rank r owns blocks start[r] .. start[r+1]-1). */
+int nnsdp_shard_plan(const nnsdp_problem* p, const nnsdp_options* o, int32_t nranks, int32_t* n_blocks, int32_t* block_n,
+                     int32_t* start);
 int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const char* id128);
 
 #ifdef __cplusplus

@@ -196,6 +196,51 @@ __global__ void k_symmetrize_lower(int n, int ld, double* A) {
 
 using namespace nnsdp;
 
+// PSD blocks the solver works on: the reference's index sets (makeCliques / setupZs!) mapped through the normalisation
+// (eliminated coordinates dropped), identical sets merged - a sum of NSD matrices on one index set is NSD, so one block
+// per distinct set is an equivalent feasible set.  Host only.
+static std::vector<std::vector<int>> reduced_cliques(const ProblemCopy& P, const Congruence& C, int decomp_mode) {
+  auto cl_full = clique_index_sets(P.K, P.xdims.data(), P.beta, decomp_mode);
+  std::vector<std::vector<int>> cl;
+  for (auto& cq : cl_full) {
+    std::vector<int> r;
+    for (int i : cq)
+      if (C.newpos[i] >= 0) r.push_back(C.newpos[i]);
+    std::sort(r.begin(), r.end());
+    r.erase(std::unique(r.begin(), r.end()), r.end());
+    if (std::find(cl.begin(), cl.end(), r) == cl.end()) cl.push_back(r);
+  }
+  return cl;
+}
+
+// clique-sharded mode: contiguous block ranges per rank, balanced by n_k^3 (blocks k, k+1 overlap, so neighbours stay
+// on one rank); start has nranks + 1 entries, rank r owns blocks [start[r], start[r+1]).  Host only.
+static std::vector<int> shard_ranges(const std::vector<int>& cn, int nr) {
+  // linear partition: contiguous ranges minimising the heaviest rank's sum of n_k^3 (the iteration's critical path is
+  // the slowest rank's projection launch); exact dynamic programme, ncl and nr are tiny
+  const int ncl = (int)cn.size();
+  std::vector<double> pre(ncl + 1, 0.0);
+  for (int k = 0; k < ncl; ++k) pre[k + 1] = pre[k] + (double)cn[k] * cn[k] * cn[k];
+  const int parts = std::min(nr, std::max(ncl, 1));
+  const double inf = 1e300;
+  // best[r][k]: minimal bottleneck of the first k blocks in r non-empty ranges
+  std::vector<std::vector<double>> best(parts + 1, std::vector<double>(ncl + 1, inf));
+  std::vector<std::vector<int>> cut(parts + 1, std::vector<int>(ncl + 1, 0));
+  best[0][0] = 0.0;
+  for (int r = 1; r <= parts; ++r)
+    for (int k = r; k <= ncl; ++k)
+      for (int j = r - 1; j < k; ++j) {
+        double v = std::max(best[r - 1][j], pre[k] - pre[j]);
+        if (v < best[r][k]) { best[r][k] = v; cut[r][k] = j; }
+      }
+  std::vector<int> start(nr + 1, ncl);
+  int k = ncl;
+  for (int r = parts; r >= 1; --r) { k = (ncl > 0) ? cut[r][k] : 0; start[r - 1] = k; }
+  start[0] = 0;
+  for (int r = parts; r <= nr; ++r) start[r] = ncl;     // more ranks than blocks: the surplus ranks own nothing
+  return start;
+}
+
 struct nnsdp_solver {
   nnsdp_options opt;
   ProblemCopy P;
@@ -266,18 +311,7 @@ struct nnsdp_solver {
     HIPCHK(hipStreamCreate(&st));
     if (!(opt.interval_guard >= 0.0 && opt.interval_guard < 0.1)) throw std::invalid_argument("interval_guard must be in [0, 0.1)");
     C = make_congruence(P, opt.normalize != 0, opt.interval_guard);
-    auto cl_full = clique_index_sets(P.K, P.xdims.data(), P.beta, opt.decomp_mode);
-    std::vector<std::vector<int>> cl;
-    for (auto& cq : cl_full) {
-      std::vector<int> r;
-      for (int i : cq)
-        if (C.newpos[i] >= 0) r.push_back(C.newpos[i]);
-      std::sort(r.begin(), r.end());
-      r.erase(std::unique(r.begin(), r.end()), r.end());
-      // identical index sets constrain the same block: a sum of NSD matrices on one index set is
-      // NSD, so one block per distinct set is an equivalent feasible set
-      if (std::find(cl.begin(), cl.end(), r) == cl.end()) cl.push_back(r);
-    }
+    std::vector<std::vector<int>> cl = reduced_cliques(P, C, opt.decomp_mode);
     Pattern pt = build_pattern(C.nred, cl);
     Operator op;
     try {
@@ -393,19 +427,7 @@ struct nnsdp_solver {
     std::memcpy(uid.internal, id128, 128);
     R.check(R.CommInitRank(&comm, nr, uid, rk), "ncclCommInitRank");
     nranks = nr; rank = rk;
-    // contiguous clique ranges balanced by n_k^3 (cliques k, k+1 overlap, so neighbours stay together)
-    std::vector<double> cost(ncl);
-    double tot = 0;
-    for (int k = 0; k < ncl; ++k) { cost[k] = (double)cn[k] * cn[k] * cn[k]; tot += cost[k]; }
-    std::vector<int> start(nr + 1, ncl);
-    start[0] = 0;
-    double accum = 0;
-    int r = 1;
-    for (int k = 0; k < ncl && r < nr; ++k) {
-      accum += cost[k];
-      if (accum >= tot * r / nr) start[r++] = k + 1;
-    }
-    for (; r < nr; ++r) start[r] = ncl;
+    std::vector<int> start = shard_ranges(cn, nr);
     k0 = start[rk]; k1 = start[rk + 1];
     // source lists restricted to the owned cliques
     std::vector<int> sp = d_sptr.download();
@@ -478,7 +500,17 @@ struct nnsdp_solver {
     hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
                        d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr, coff[k0], coff[k1],
                        (!comm || rank == 0) ? 1 : 0);
-    if (check && comm) allreduce(acc.p, 3);       // residual sums of the clique blocks live on their owners
+    if (check && comm) {
+      // every stopping / adaptation decision is taken from these 8 numbers, so they must be bit-identical on all ranks:
+      // [0..2] residual sums of the clique blocks live on their owners (multiplier block counted on rank 0 only);
+      // [3..6] are computed redundantly everywhere (atomics: rounding differs between ranks) - rank 0's copy is used;
+      // [7] is the time-limit flag of any rank.  One all-reduce distributes all of them.
+      if (rank != 0) HIPCHK(hipMemsetAsync(acc.p + 3, 0, 4 * sizeof(double), st));
+      const double tflag = (opt.max_time > 0 && loop_t0 > 0 && now_s() - loop_t0 > opt.max_time) ? 1.0 : 0.0;
+      tflag_host = tflag;
+      HIPCHK(hipMemcpyAsync(acc.p + 7, &tflag_host, sizeof(double), hipMemcpyHostToDevice, st));
+      allreduce(acc.p, 8);
+    }
     HIPCHK(hipGetLastError());
   }
 
@@ -538,6 +570,7 @@ struct nnsdp_solver {
   // one iteration with residual accumulation; fills last_*.  Split in two so that a batch handle can have the
   // check iterations of several SDPs in flight on their streams at once.
   double acc_host[8];
+  double tflag_host = 0.0, loop_t0 = 0.0;
   void check_enqueue() {
     enqueue_iteration(true, next_is_warm());
     ++iters_done;
@@ -620,7 +653,7 @@ struct nnsdp_solver {
         }
       }
     }
-    if (!advance_only && opt.max_time > 0 && now_s() - t0 > opt.max_time) return NNSDP_STATUS_TIME_LIMIT;
+    if (!advance_only && opt.max_time > 0 && (comm ? acc_host[7] > 0.0 : now_s() - t0 > opt.max_time)) return NNSDP_STATUS_TIME_LIMIT;
     // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
     {
       double worst = std::max(last_pres, last_dres);
@@ -641,6 +674,7 @@ struct nnsdp_solver {
     double t0 = now_s();
     int status = NNSDP_STATUS_ITERATION_LIMIT;
     const bool advance_only = cap >= 0;
+    loop_t0 = advance_only ? 0.0 : t0;
     const long long limit = advance_only ? iters_done + cap : (long long)opt.max_iters;
     int ce = opt.check_every;
     loop_begin();
@@ -1379,6 +1413,26 @@ int nnsdp_comm_unique_id(char* id128) {
   Rccl::UniqueId uid;
   R.check(R.GetUniqueId(&uid), "ncclGetUniqueId");
   std::memcpy(id128, uid.internal, 128);
+  API_END
+}
+
+int nnsdp_shard_plan(const nnsdp_problem* p, const nnsdp_options* o, int32_t nranks, int32_t* n_blocks, int32_t* block_n,
+                     int32_t* start) {
+  API_BEGIN
+  if (!p || !o || !n_blocks) throw std::invalid_argument("null argument");
+  if (nranks < 1) throw std::invalid_argument("nranks must be >= 1");
+  if (o->decomp_mode < NNSDP_DECOMP_DENSE || o->decomp_mode > NNSDP_DECOMP_PATH) throw std::invalid_argument("unrecognized decomp_mode");
+  ProblemCopy P;
+  P.load(p);
+  Congruence C = make_congruence(P, o->normalize != 0, o->interval_guard);
+  auto cl = reduced_cliques(P, C, o->decomp_mode);
+  *n_blocks = (int32_t)cl.size();
+  if (block_n || start) {
+    std::vector<int> cn(cl.size());
+    for (size_t k = 0; k < cl.size(); ++k) cn[k] = (int)cl[k].size();
+    if (block_n) for (size_t k = 0; k < cn.size(); ++k) block_n[k] = cn[k];
+    if (start) { auto st = shard_ranges(cn, nranks); for (int r = 0; r <= nranks; ++r) start[r] = st[r]; }
+  }
   API_END
 }
 

@@ -448,6 +448,21 @@ class Solver:
             pass
 
 
+def shardPlan(query, opts: AdmmSdpOptions, nranks: int):
+    """(block dimensions, start) - the PSD blocks the solver works on and their contiguous partition over `nranks` ranks
+    (rank r owns blocks start[r] .. start[r+1]-1), as Solver.set_comm uses it.  Host only: needs no GPU."""
+    lib = _lib.load()
+    cp = _CProblem(query)
+    o = opts.to_c()
+    n = C.c_int32()
+    _lib.check(lib.nnsdp_shard_plan(C.byref(cp.p), C.byref(o), int(nranks), C.byref(n), None, None))
+    bn = np.zeros(n.value, dtype=np.int32)
+    st = np.zeros(int(nranks) + 1, dtype=np.int32)
+    _lib.check(lib.nnsdp_shard_plan(C.byref(cp.p), C.byref(o), int(nranks), C.byref(n), bn.ctypes.data_as(_lib.c_int32_p),
+                                    st.ctypes.data_as(_lib.c_int32_p)))
+    return bn.tolist(), st.tolist()
+
+
 def comm_unique_id() -> bytes:
     """RCCL unique id (128 bytes) for the clique-sharded mode; generate on rank 0, broadcast to all ranks."""
     buf = C.create_string_buffer(128)

@@ -75,19 +75,12 @@ def test_two_rank_gloo_matches_serial():
 
 
 # ----------------------------------------------------------------------------- clique-sharded mode (one SDP over ranks)
-def _shard_ranges(nk, world):
-    """contiguous clique ranges balanced by n_k^3: the partition nnsdp_solver::set_comm uses."""
-    cost = np.array(nk, dtype=float) ** 3
-    tot, acc, r = cost.sum(), 0.0, 1
-    start = [0] + [len(nk)] * world
-    for k in range(len(nk)):
-        if r >= world:
-            break
-        acc += cost[k]
-        if acc >= tot * r / world:
-            start[r] = k + 1
-            r += 1
-    return start
+def _product_plan(world):
+    """blocks and rank ranges from the PRODUCT's own partition code (nnsdp_shard_plan: the host-only entry point
+    nnsdp_solver::set_comm calls), not a re-derivation."""
+    import nnsdp_amd as na
+    q = helpers.product_query(helpers.load_problem("W10-D10", 0))
+    return na.shardPlan(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()), world)
 
 
 def _sharded_worker(rank, world, port, out):
@@ -101,7 +94,8 @@ def _sharded_worker(rank, world, port, out):
     q = helpers.oracle_query(helpers.load_problem("W10-D10", 0))
     P = oadmm.ScaledProblem(oop.build_operator(q, "single", normalize=True))
     S = oadmm.AdmmState(P, 0.1, 1.6)
-    st = _shard_ranges(S.nk, world)
+    bn, st = _product_plan(world)
+    assert bn == list(S.nk), (bn, S.nk)                      # the product solves the very blocks the oracle state holds
     own = range(st[rank], st[rank + 1])
     for _ in range(40):
         nu = S.nu
@@ -139,6 +133,25 @@ def _sharded_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def test_shard_plan_is_contiguous_balanced_and_complete():
+    import nnsdp_amd as na
+    q = helpers.product_query(helpers.load_problem("W40-D20", 0))
+    for mode in (na.SingleDecomp(), na.DoubleDecomp()):
+        o = na.AdmmSdpOptions(decomp_mode=mode)
+        bn1, st1 = na.shardPlan(q, o, 1)
+        assert st1 == [0, len(bn1)] and max(bn1) <= 128
+        cost = np.array(bn1, dtype=float) ** 3
+        for world in (2, 4, 8, 64):
+            bn, st = na.shardPlan(q, o, world)
+            assert bn == bn1 and st[0] == 0 and st[-1] == len(bn) and all(a <= b for a, b in zip(st, st[1:]))
+            load = [cost[st[r]:st[r + 1]].sum() for r in range(world)]
+            if world <= 8:
+                # the heaviest rank is the critical path: optimal linear partition, within 20 % of the ideal share here
+                assert min(load) > 0 and max(load) <= 1.2 * cost.sum() / world
+    with pytest.raises(na._lib.NnsdpError):
+        na.shardPlan(q, na.AdmmSdpOptions(), 0)
+
+
 def test_clique_sharded_iteration_matches_serial_gloo():
     from oracle import admm as oadmm, operator as oop
     s = socket.socket()
@@ -155,6 +168,7 @@ def test_clique_sharded_iteration_matches_serial_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert st[0] == 0 and 0 < st[1] < st[2] == 9              # 9 cliques of W10-D10 split over 2 ranks
+    assert st == _product_plan(2)[1]
     q = helpers.oracle_query(helpers.load_problem("W10-D10", 0))
     S = oadmm.AdmmState(oadmm.ScaledProblem(oop.build_operator(q, "single", normalize=True)), 0.1, 1.6)
     for _ in range(40):
