@@ -187,6 +187,24 @@ static double lambda_max_dense(rocblas_handle h, const DBuf<double>& Zd, int n, 
   return d.back();
 }
 
+// ---- PSD blocks above 128 (library path: rocSOLVER dsyevd + rocBLAS dgemm, one block at a time) --------------------
+// A = sym(nu_k)
+__global__ void k_big_sym(int n, const double* __restrict__ nu, double* __restrict__ A) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n) A[(size_t)j * n + i] = 0.5 * (nu[(size_t)j * n + i] + nu[(size_t)i * n + j]);
+}
+// T[:, j] = V[:, j] * max(lam_j, 0)
+__global__ void k_big_scale(int n, const double* __restrict__ V, const double* __restrict__ lam, double* __restrict__ T) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n) { double l = lam[j]; T[(size_t)j * n + i] = l > 0.0 ? l * V[(size_t)j * n + i] : 0.0; }
+}
+// nu <- w + kappa (nu - w)   (penalty change, as the LDS kernel does for its blocks)
+__global__ void k_big_rescale(long long n2, const double* __restrict__ w, double* __restrict__ nu, const double* __restrict__ kappa) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double kap = *kappa;
+  if (i < n2 && kap != 1.0) { double wv = w[i]; nu[i] = wv + kap * (nu[i] - wv); }
+}
+
 __global__ void k_symmetrize_lower(int n, int ld, double* A) {
   int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
   if (i < n && i > j) A[(size_t)i * ld + j] = A[(size_t)j * ld + i];  // copy lower (col j,row i) to upper
@@ -251,13 +269,18 @@ struct nnsdp_solver {
   std::vector<int> cn;
   std::vector<long long> coff;
   long long nmat = 0;
-  int ncl = 0, nmax = 0;
+  int ncl = 0, nmax = 0, nmax_small = 0;
+  std::vector<int> small_idx, big_idx;          // blocks for the LDS kernel (n <= 128) / for the library path
+  DBuf<int> d_cn_s;
+  DBuf<long long> d_coff_s;
+  DBuf<double> big_A, big_T, big_D, big_E;
+  DBuf<rocblas_int> big_info;
   bool v_lds = true;
   int proj_alg = 0;
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
-  DBuf<int> d_cn, d_sptr, d_stats, d_long;
+  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_pend;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -336,12 +359,26 @@ struct nnsdp_solver {
       nmax = std::max(nmax, cn[k]);
     }
     coff[ncl] = nmat;
-    if (nmax > 128 && opt.decomp_mode != NNSDP_DECOMP_DENSE)
-      throw std::invalid_argument("clique larger than 128 is not supported by the LDS-resident projection kernel");
-    if (nmax > 128) throw std::invalid_argument("dense mode supports Zdim <= 128 only (use a chordal decomp_mode)");
-    proj_alg = proj_algorithm(nmax);
-    v_lds = proj_lds_bytes(nmax, true, proj_alg) <= 160 * 1024;
-    lds_bytes = proj_lds_bytes(nmax, v_lds, proj_alg);
+    // blocks up to 128 go to the LDS-resident Jacobi kernel (one launch for all of them); larger ones - the reference's
+    // 151-wide cliques of width-50 nets (chordal_cliques.jl:33-36), the single Zdim x Zdim cone of DeepSdpOptions
+    // (deep_sdp.jl:57) - are projected one at a time through rocSOLVER dsyevd + rocBLAS dgemm
+    nmax_small = 0;
+    for (int k = 0; k < ncl; ++k) {
+      if (cn[k] <= 128) { small_idx.push_back(k); nmax_small = std::max(nmax_small, cn[k]); }
+      else big_idx.push_back(k);
+    }
+    if (!big_idx.empty()) {
+      std::vector<int> cs;
+      std::vector<long long> os;
+      for (int k : small_idx) { cs.push_back(cn[k]); os.push_back(coff[k]); }
+      if (cs.empty()) { cs.push_back(1); os.push_back(0); }
+      d_cn_s.upload(cs); d_coff_s.upload(os);
+      big_A.alloc((size_t)nmax * nmax); big_T.alloc((size_t)nmax * nmax); big_D.alloc(nmax); big_E.alloc(nmax); big_info.alloc(1);
+    }
+    const int nsm = std::max(nmax_small, 1);
+    proj_alg = proj_algorithm(nsm);
+    v_lds = proj_lds_bytes(nsm, true, proj_alg) <= 160 * 1024;
+    lds_bytes = proj_lds_bytes(nsm, v_lds, proj_alg);
     // gather sources: entry e <- (clique k, lower element (i,j))
     std::vector<int> sptr(S.NE + 1, 0);
     for (int k = 0; k < ncl; ++k) {
@@ -371,6 +408,7 @@ struct nnsdp_solver {
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
     d_stats.alloc(4); d_stats.zero();
+    d_pend.alloc(1); d_pend.zero();
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -422,6 +460,7 @@ struct nnsdp_solver {
   void set_comm(int nr, int rk, const char* id128) {
     if (nr < 1 || rk < 0 || rk >= nr || !id128) throw std::invalid_argument("bad communicator arguments");
     if (iters_done != 0) throw std::invalid_argument("set_comm must be called before the first iteration");
+    if (!big_idx.empty()) throw std::invalid_argument("clique-sharded mode needs every PSD block <= 128");
     Rccl& R = Rccl::get();
     Rccl::UniqueId uid;
     std::memcpy(uid.internal, id128, 128);
@@ -457,7 +496,27 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
+    a.pend = d_pend.p; a.x = x.p; a.gidx = d_gidx.p; a.alpha = opt.alpha;
+    if (big_idx.empty()) {
+      if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
+      return;
+    }
+    if (!small_idx.empty()) {
+      a.cn = d_cn_s.p; a.coff = d_coff_s.p;
+      nnsdp::launch_proj(a, (int)small_idx.size(), nmax_small, v_lds, lds_bytes, st, proj_alg);
+    }
+    for (int k : big_idx) {
+      const int n = cn[k];
+      double* nuk = nu.p + S.ng + coff[k];
+      double* wk = w.p + S.ng + coff[k];
+      hipLaunchKernelGGL(k_big_sym, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, nuk, big_A.p);
+      RBCHK(rocsolver_dsyevd(roc->h, rocblas_evect_original, rocblas_fill_lower, n, big_A.p, n, big_D.p, big_E.p, big_info.p));
+      hipLaunchKernelGGL(k_big_scale, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, big_A.p, big_D.p, big_T.p);
+      const double one = 1.0, zero = 0.0;
+      RBCHK(rocblas_dgemm(roc->h, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, big_T.p, n, big_A.p, n, &zero, wk, n));
+      hipLaunchKernelGGL(k_big_rescale, dim3(cdiv((long long)n * n, 256)), dim3(256), 0, st, (long long)n * n, wk, nuk, d_kappa());
+    }
+    HIPCHK(hipGetLastError());
   }
 
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
@@ -466,6 +525,21 @@ struct nnsdp_solver {
     if (e0) HIPCHK(hipEventRecord(e0, st));
     enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
+    static const bool no_fuse = [] { const char* e = std::getenv("NNSDP_NO_FUSE"); return e && std::atoi(e) != 0; }();   // diagnostic: 6 launches
+    if (!check && !comm && !no_fuse && big_idx.empty()) {
+      // plain iteration, 4 launches: projection (applies the deferred clique part of the previous nu-update while it
+      // loads its matrix) -> gather + A' -> M^-1 -> A + multiplier part of the nu-update (defers the clique part)
+      const int nat = cdiv((long long)ng * 64, kThreads);
+      hipLaunchKernelGGL(k_gather_At, dim3(nat + cdiv(NE, kThreads)), dim3(kThreads), 0, st, nat, NE, ng, d_sptr.p, d_soff.p, d_isdiag.p,
+                         nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p, D.csc_ptr.p, D.csc_row.p, D.csc_val.p, nu.p, D.c.p,
+                         d_kappa(), p.p, qv.p);
+      hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
+      const int nreg = cdiv((long long)NE * kRowLanes, kThreads);
+      hipLaunchKernelGGL(k_Ax_upd, dim3(nreg + nlong + cdiv(ng, kThreads)), dim3(kThreads), 0, st, NE, nreg, nlong, d_long.p, D.csr_ptr.p,
+                         D.csr_col.p, D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p, ng, p.p, D.c.p, nu.p, opt.alpha, d_kappa(), d_pend.p);
+      HIPCHK(hipGetLastError());
+      return;
+    }
     if (comm) {
       hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                          nu.p + ng, w.p + ng, 0, hsum.p);
@@ -499,7 +573,7 @@ struct nnsdp_solver {
                          x.p, d_sigma(), acc.p);
     hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
                        d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr, coff[k0], coff[k1],
-                       (!comm || rank == 0) ? 1 : 0);
+                       (!comm || rank == 0) ? 1 : 0, d_pend.p);
     if (check && comm) {
       // every stopping / adaptation decision is taken from these 8 numbers, so they must be bit-identical on all ranks:
       // [0..2] residual sums of the clique blocks live on their owners (multiplier block counted on rank 0 only);
@@ -555,7 +629,7 @@ struct nnsdp_solver {
     while (left > 0) {
       bool can_warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
       static const bool no_graph = [] { const char* e = std::getenv("NNSDP_NO_GRAPH"); return e && std::atoi(e) != 0; }();   // diagnostic: eager launches only
-      if (!no_graph && !comm && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
+      if (!no_graph && !comm && big_idx.empty() && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
         build_graph(kGraphIters);
         HIPCHK(hipGraphLaunch(gexec, st));
         since_cold += kGraphIters; iters_done += kGraphIters; left -= kGraphIters;
@@ -939,7 +1013,7 @@ struct nnsdp_batch {
   int nblocks = 0, nmax = 0, alg = 0;
   bool v_lds = true;
   size_t lds = 0;
-  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
+  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0, gx_mul = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   static constexpr int kGraphIters = 8;
@@ -955,6 +1029,7 @@ struct nnsdp_batch {
     for (int i = 0; i < count; ++i) {
       if (!sv[i]) throw std::invalid_argument("null solver in batch");
       if (sv[i]->comm) throw std::invalid_argument("clique-sharded solvers cannot be batched");
+      if (!sv[i]->big_idx.empty()) throw std::invalid_argument("solvers with PSD blocks above 128 cannot be batched");
       if (sv[i]->opt.device != sv[0]->opt.device) throw std::invalid_argument("batched solvers must live on one device");
       if (sv[i]->opt.check_every != sv[0]->opt.check_every) throw std::invalid_argument("batched solvers must share check_every");
       for (int j = 0; j < i; ++j) if (sv[j] == sv[i]) throw std::invalid_argument("a solver appears twice in the batch");
@@ -974,7 +1049,7 @@ struct nnsdp_batch {
     std::vector<IterArgs> it;
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
-    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = 0;
+    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = gx_mul = 0;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
       HIPCHK(hipStreamSynchronize(s->st));
@@ -987,7 +1062,7 @@ struct nnsdp_batch {
       a.longrows = s->d_long.p; a.gidx = s->d_gidx.p;
       a.z0 = s->D.z0.p; a.Dinv = s->D.Dinv.p; a.c = s->D.c.p; a.Minv = s->Minv.p;
       a.nu = s->nu.p; a.w = s->w.p; a.g = s->g.p; a.p = s->p.p; a.qv = s->qv.p; a.ww = s->ww.p; a.x = s->x.p;
-      a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
+      a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha; a.pend = s->d_pend.p;
       {
         const size_t nb = (size_t)(a.ng + 63) / 64;
         if (s->symv_part.n != nb * nb * 64) s->symv_part.alloc(nb * nb * 64);
@@ -1001,6 +1076,7 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
+      q.pend = s->d_pend.p; q.x = s->x.p; q.gidx = s->d_gidx.p; q.alpha = s->opt.alpha;   // a solver may arrive with a deferred update
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));
@@ -1011,6 +1087,7 @@ struct nnsdp_batch {
       gx_ax = std::max(gx_ax, cdiv((long long)a.NE * kRowLanes, kThreads));
       gx_long = std::max(gx_long, a.nlong);
       gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
+      gx_mul = std::max(gx_mul, cdiv(a.ng, kThreads));
     }
     nblocks = (int)map.size();
     alg = proj_algorithm(nmax);
@@ -1023,6 +1100,20 @@ struct nnsdp_batch {
   void enqueue_iteration(bool warm) {
     const int B = (int)act.size();
     if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
+    static const bool no_fuse = [] { const char* e = std::getenv("NNSDP_NO_FUSE"); return e && std::atoi(e) != 0; }();   // diagnostic
+    static const bool full_gemv0 = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();
+    if (!no_fuse) {
+      // same 4-stage iteration as nnsdp_solver::enqueue_iteration, one launch per stage for all SDPs
+      hipLaunchKernelGGL(k_gather_At_b, dim3(gx_at + gx_gather, B), dim3(kThreads), 0, st, d_it.p, gx_at);
+      if (full_gemv0) hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
+      else {
+        hipLaunchKernelGGL(k_symv_tiles_b, dim3(gx_tiles, B), dim3(kThreads), 0, st, d_it.p);
+        hipLaunchKernelGGL(k_symv_reduce_b, dim3(gx_nb, B), dim3(64), 0, st, d_it.p);
+      }
+      hipLaunchKernelGGL(k_Ax_upd_b, dim3(gx_ax + gx_long + gx_mul, B), dim3(kThreads), 0, st, d_it.p, gx_ax, gx_long);
+      HIPCHK(hipGetLastError());
+      return;
+    }
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
     static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic

@@ -55,7 +55,7 @@ def main():
             w = csv.writer(fh)
             w.writerow(["it", "c_gamma", "lower_bound", "pinf", "dinf", "rel_gap", "mu"])
             for h in r.history:
-                w.writerow([h["it"], repr(h["obj"]), repr(h["lower"]), h["pinf"], h["dinf"], h["gap"], h["mu"]])
+                w.writerow([h["it"], repr(float(h["obj"])), repr(float(h["lower"])), h["pinf"], h["dinf"], h["gap"], h["mu"]])
         with open(out_json, "w") as fh:
             json.dump(res, fh, indent=1, sort_keys=True)
 

@@ -351,8 +351,7 @@ def test_acas_shaped_safety_query_tracks_oracle():
     """BASELINE configs[4] kind of query: no ACAS file is in the reference checkout, so a synthetic 5-40x6-5 ReLU
     net (scripts/make_networks.jl distribution), box of half-width 0.05, hyperplane safety S (Utils/qc.jl:27-37),
     objective sum(gamma) (deep_sdp.jl:25).  GPU ADMM vs oracle ADMM after the same number of iterations.
-    (The real ACAS width of 50 gives 151-wide cliques; safety queries keep every coordinate, and blocks above
-    128 do not fit the LDS-resident projection kernel: refused with an error)"""
+    (The real ACAS width of 50 gives 151-wide cliques: see the blocks-above-128 tests below.)"""
     from oracle import nnet_io, qc as oqc
     net = nnet_io.random_net([5] + [40] * 6 + [5], seed=1234)
     x0 = np.full(5, 0.3)
@@ -370,9 +369,7 @@ def test_acas_shaped_safety_query_tracks_oracle():
                           qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_safety=na.QcSafety(S=S),
                           qc_activs=[na.QcActivBounded(acymin=np.zeros(300), acymax=np.ones(300)),
                                      na.QcActivSector(acxdim=300, beta=0, smin=np.zeros(300), smax=np.ones(300))])
-    with pytest.raises(na._lib.NnsdpError) as ei:
-        na.runQuery(acas, na.AdmmSdpOptions(max_iters=10))
-    assert "128" in str(ei.value) and ei.value.code < 0
+    # (blocks above 128 run through the library path: test_blocks_above_128_width_50_safety_query_in_the_reference_cliques)
     # the path decomposition (extension, exact for hyperplane safety sets: S12 = 0) keeps width-50 blocks at 2W+1 = 101
     sp = na.runQuery(acas, na.AdmmSdpOptions(max_iters=60, decomp_mode=na.PathDecomp()))
     assert sp.summary["max_clique"] <= 103 and np.isfinite(sp.objective_value)
@@ -491,6 +488,49 @@ def test_solver_argument_errors():
         assert ei.value.code < 0
     with pytest.raises(ValueError):
         na.makeZ(q, np.zeros(5))
-    # Zdim 803 as ONE dense cone does not fit the LDS-resident kernel: refused, not silently slow
-    with pytest.raises(na._lib.NnsdpError):
-        na.runQuery(helpers.product_query(helpers.load_problem("W40-D20", 0)), na.AdmmSdpOptions(decomp_mode=na.DenseCone(), normalize=False, max_iters=10))
+    for bad in (dict(interval_guard=-1.0), dict(interval_guard=0.5)):
+        with pytest.raises(na._lib.NnsdpError):
+            na.runQuery(q, na.AdmmSdpOptions(**bad))
+
+
+def test_blocks_above_128_dense_cone_w10_d20_tracks_oracle():
+    """DeepSdpOptions' single cone (src/Methods/deep_sdp.jl:57) on W10-D20: Zdim 203 > 128, so the block goes through the
+    library path (rocSOLVER dsyevd + rocBLAS dgemm) instead of the LDS-resident Jacobi kernel.  Same iterates as the oracle
+    ADMM on the dense cone, and the same optimum as the Double decomposition of the same problem."""
+    d = helpers.load_problem("W10-D20", 0)
+    q, qo = helpers.product_query(d), helpers.oracle_query(d)
+    iters = 300
+    s = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DenseCone(), max_iters=iters, polish=False))
+    assert s.summary["n_cliques"] == 1 and s.summary["max_clique"] > 128
+    r = oadmm.admm_solve(oop.build_operator(qo, "dense", normalize=True), oadmm.AdmmOptions(max_iters=iters))
+    assert s.summary["iters"] == r.iters
+    assert abs(s.objective_value - r.objective) <= 1e-6 * abs(r.objective) + 1e-9
+    # unnormalised (the reference's coordinates verbatim): one 203 x 203 cone
+    s0 = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DenseCone(), normalize=False, max_iters=100, polish=False))
+    r0 = oadmm.admm_solve(oop.build_operator(qo, "dense", normalize=False), oadmm.AdmmOptions(max_iters=100))
+    assert s0.summary["max_clique"] == 203
+    assert abs(s0.objective_value - r0.objective) <= 1e-6 * abs(r0.objective) + 1e-9
+
+
+def test_blocks_above_128_width_50_safety_query_in_the_reference_cliques():
+    """the 5-50x6-5 (ACAS-Xu shaped) safety query in the reference's OWN Single / Double cliques (106, 151 x 4;
+    chordal_cliques.jl:33-36) - blocks of 151 > 128: library path for those, LDS kernel for the rest - against the oracle."""
+    from oracle import nnet_io, qc as oqc
+    net = nnet_io.random_net([5] + [50] * 6 + [5], seed=1)
+    x0 = np.full(5, 0.3)
+    lo, hi = x0 - 0.05, x0 + 0.05
+    y0 = nnet_io.eval_net(net, x0)
+    normal = np.zeros(5); normal[0] = 1.0
+    S = oqc.hplane_S(normal, float(y0[0]) + 5.0, net)
+    qo = oqc.make_safety_query(net, lo, hi, 0, S)
+    q = na.SafetyQuery(ffnet=na.FeedFwdNet(xdims=net.xdims, Ms=net.Ms), qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_safety=na.QcSafety(S=S),
+                       qc_activs=[na.QcActivBounded(acymin=qo.qc_bounded.acymin, acymax=qo.qc_bounded.acymax),
+                                  na.QcActivSector(acxdim=300, beta=0, smin=qo.qc_sector.smin, smax=qo.qc_sector.smax)])
+    for mode, oname in ((na.SingleDecomp(), "single"), (na.DoubleDecomp(), "double")):
+        iters = 150
+        s = na.runQuery(q, na.AdmmSdpOptions(max_iters=iters, decomp_mode=mode, polish=False))
+        r = oadmm.admm_solve(oop.build_operator(qo, oname, normalize=True), oadmm.AdmmOptions(max_iters=iters))
+        assert s.summary["iters"] == r.iters
+        assert abs(s.objective_value - r.objective) <= 1e-5 * abs(r.objective) + 1e-9, (oname, s.objective_value, r.objective)
+        if oname == "single":
+            assert s.summary["max_clique"] == 151 and s.summary["n_cliques"] == 5

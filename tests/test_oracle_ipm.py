@@ -60,4 +60,4 @@ def test_ipm_trace_reproduces_the_published_values_at_a_loose_gap():
     for p in pub:
         i = np.nonzero(tail & (obj <= p))[0][0]           # first iterate at or below the published value
         assert 5e-5 <= gap[i] <= 5e-4, (p, gap[i])
-    assert abs(obj[-1] - GOLD["W10-D10_b0"]["rho"]) <= 1e-8
+    assert abs(obj[-1] - GOLD["W10-D10_b0"]["rho"]) <= 1e-6 * obj[-1]      # the committed optimum is the best iterate of this trace
