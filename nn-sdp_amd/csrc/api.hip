@@ -280,7 +280,7 @@ struct nnsdp_solver {
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
-  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_pend;
+  DBuf<int> d_cn, d_sptr, d_stats, d_long;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -408,7 +408,6 @@ struct nnsdp_solver {
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
     d_stats.alloc(4); d_stats.zero();
-    d_pend.alloc(1); d_pend.zero();
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -496,7 +495,6 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    a.pend = d_pend.p; a.x = x.p; a.gidx = d_gidx.p; a.alpha = opt.alpha;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
@@ -525,21 +523,6 @@ struct nnsdp_solver {
     if (e0) HIPCHK(hipEventRecord(e0, st));
     enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
-    static const bool no_fuse = [] { const char* e = std::getenv("NNSDP_NO_FUSE"); return e && std::atoi(e) != 0; }();   // diagnostic: 6 launches
-    if (!check && !comm && !no_fuse && big_idx.empty()) {
-      // plain iteration, 4 launches: projection (applies the deferred clique part of the previous nu-update while it
-      // loads its matrix) -> gather + A' -> M^-1 -> A + multiplier part of the nu-update (defers the clique part)
-      const int nat = cdiv((long long)ng * 64, kThreads);
-      hipLaunchKernelGGL(k_gather_At, dim3(nat + cdiv(NE, kThreads)), dim3(kThreads), 0, st, nat, NE, ng, d_sptr.p, d_soff.p, d_isdiag.p,
-                         nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p, D.csc_ptr.p, D.csc_row.p, D.csc_val.p, nu.p, D.c.p,
-                         d_kappa(), p.p, qv.p);
-      hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
-      const int nreg = cdiv((long long)NE * kRowLanes, kThreads);
-      hipLaunchKernelGGL(k_Ax_upd, dim3(nreg + nlong + cdiv(ng, kThreads)), dim3(kThreads), 0, st, NE, nreg, nlong, d_long.p, D.csr_ptr.p,
-                         D.csr_col.p, D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p, ng, p.p, D.c.p, nu.p, opt.alpha, d_kappa(), d_pend.p);
-      HIPCHK(hipGetLastError());
-      return;
-    }
     if (comm) {
       hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                          nu.p + ng, w.p + ng, 0, hsum.p);
@@ -573,7 +556,7 @@ struct nnsdp_solver {
                          x.p, d_sigma(), acc.p);
     hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
                        d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr, coff[k0], coff[k1],
-                       (!comm || rank == 0) ? 1 : 0, d_pend.p);
+                       (!comm || rank == 0) ? 1 : 0);
     if (check && comm) {
       // every stopping / adaptation decision is taken from these 8 numbers, so they must be bit-identical on all ranks:
       // [0..2] residual sums of the clique blocks live on their owners (multiplier block counted on rank 0 only);
@@ -1013,7 +996,7 @@ struct nnsdp_batch {
   int nblocks = 0, nmax = 0, alg = 0;
   bool v_lds = true;
   size_t lds = 0;
-  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0, gx_mul = 0;
+  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   static constexpr int kGraphIters = 8;
@@ -1049,7 +1032,7 @@ struct nnsdp_batch {
     std::vector<IterArgs> it;
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
-    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = gx_mul = 0;
+    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = 0;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
       HIPCHK(hipStreamSynchronize(s->st));
@@ -1062,7 +1045,7 @@ struct nnsdp_batch {
       a.longrows = s->d_long.p; a.gidx = s->d_gidx.p;
       a.z0 = s->D.z0.p; a.Dinv = s->D.Dinv.p; a.c = s->D.c.p; a.Minv = s->Minv.p;
       a.nu = s->nu.p; a.w = s->w.p; a.g = s->g.p; a.p = s->p.p; a.qv = s->qv.p; a.ww = s->ww.p; a.x = s->x.p;
-      a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha; a.pend = s->d_pend.p;
+      a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
       {
         const size_t nb = (size_t)(a.ng + 63) / 64;
         if (s->symv_part.n != nb * nb * 64) s->symv_part.alloc(nb * nb * 64);
@@ -1076,7 +1059,6 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
-      q.pend = s->d_pend.p; q.x = s->x.p; q.gidx = s->d_gidx.p; q.alpha = s->opt.alpha;   // a solver may arrive with a deferred update
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));
@@ -1087,7 +1069,6 @@ struct nnsdp_batch {
       gx_ax = std::max(gx_ax, cdiv((long long)a.NE * kRowLanes, kThreads));
       gx_long = std::max(gx_long, a.nlong);
       gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
-      gx_mul = std::max(gx_mul, cdiv(a.ng, kThreads));
     }
     nblocks = (int)map.size();
     alg = proj_algorithm(nmax);
@@ -1100,20 +1081,6 @@ struct nnsdp_batch {
   void enqueue_iteration(bool warm) {
     const int B = (int)act.size();
     if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
-    static const bool no_fuse = [] { const char* e = std::getenv("NNSDP_NO_FUSE"); return e && std::atoi(e) != 0; }();   // diagnostic
-    static const bool full_gemv0 = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();
-    if (!no_fuse) {
-      // same 4-stage iteration as nnsdp_solver::enqueue_iteration, one launch per stage for all SDPs
-      hipLaunchKernelGGL(k_gather_At_b, dim3(gx_at + gx_gather, B), dim3(kThreads), 0, st, d_it.p, gx_at);
-      if (full_gemv0) hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
-      else {
-        hipLaunchKernelGGL(k_symv_tiles_b, dim3(gx_tiles, B), dim3(kThreads), 0, st, d_it.p);
-        hipLaunchKernelGGL(k_symv_reduce_b, dim3(gx_nb, B), dim3(64), 0, st, d_it.p);
-      }
-      hipLaunchKernelGGL(k_Ax_upd_b, dim3(gx_ax + gx_long + gx_mul, B), dim3(kThreads), 0, st, d_it.p, gx_ax, gx_long);
-      HIPCHK(hipGetLastError());
-      return;
-    }
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
     static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic

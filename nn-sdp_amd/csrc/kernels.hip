@@ -65,12 +65,6 @@ struct ProjArgs {
   int warm;               // 1: use Vg as the starting basis
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
-  // deferred nu-update of the previous iteration (fused iterations, see k_Ax_upd): when *pend != 0 the block first applies
-  // nu_k += alpha (x[gidx] wgt - w_k) to its own matrix, exactly what k_update_nu would have done.  pend may be null.
-  const int* pend = nullptr;
-  const double* x = nullptr;
-  const unsigned int* gidx = nullptr;   // pattern entry of every element of the packed clique storage, bit 31 = diagonal
-  double alpha = 0.0;
 };
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
@@ -243,22 +237,6 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 #ifdef NNSDP_STAMPS
   long long sec_t[6]; sec_t[0] = clock64();
 #endif
-  if (a.pend && *a.pend) {
-    // deferred update of the previous (fused) iteration, same arithmetic as k_update_nu; the block owns these elements
-    const unsigned int* gi = a.gidx + a.coff[k];
-    double* nu0 = a.nu + a.coff[k];
-    const double* w0 = a.w + a.coff[k];
-    const double al = a.alpha;
-    for (int idx = tid; idx < n * n; idx += NT) {
-      const unsigned int gv = gi[idx];
-      double xv = a.x[gv & 0x7fffffffu];
-      if (!(gv >> 31)) xv *= kInvSqrt2;
-      const double wv = w0[idx];
-      const double res = xv - wv;
-      nu0[idx] += al * res;
-    }
-    __syncthreads();
-  }
   // ---- load: A = sym(nu_k) (full, both triangles, for the warm-start products), padded row/col zero; starting basis
   double fro2 = 0.0;
   const bool warm = a.warm != 0;
@@ -1403,7 +1381,6 @@ struct IterArgs {
   const double* sigma; double* kappa;
   double alpha;
   double* symv_part;     // [nb][nb][64] partial products of the tiled symmetric M^-1 q (batch handles), nb = ceil(ng / 64)
-  int* pend;             // deferred-update flag of this SDP (see ProjArgs.pend)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1486,72 +1463,6 @@ __global__ __launch_bounds__(kThreads) void k_finish_g(int NE, const double* __r
                                                         double* __restrict__ g) {
   int e = blockIdx.x * kThreads + threadIdx.x;
   if (e < NE) g[e] = Dinv[e] * (z0[e] / (*sigma) + h[e]);
-}
-
-// Fused gather + A' (one launch instead of two): blocks [0, nat) hold one wave per multiplier and evaluate g[e] on the
-// fly for every nonzero of their column (same arithmetic and order as gather_g_body, so the value is the one the
-// gather blocks store); blocks [nat, ...) are the plain gather that writes g for the later x = g - Dinv A ww.
-__device__ __forceinline__ double gather_val(int e, const int* __restrict__ sptr, const long long* __restrict__ soff,
-                                             const unsigned char* __restrict__ isdiag, const double* __restrict__ nuk,
-                                             const double* __restrict__ wk, const double* __restrict__ z0,
-                                             const double* __restrict__ Dinv, double sg) {
-  double s = 0.0;
-  for (int q = sptr[e]; q < sptr[e + 1]; ++q) { long long o = soff[q]; s += 2.0 * wk[o] - nuk[o]; }
-  if (!isdiag[e]) s *= kSqrt2;
-  return Dinv[e] * (z0[e] / sg + s);
-}
-__device__ __forceinline__ void gather_At_body(const int bid, const int nat, int NE, int ng, const int* __restrict__ sptr,
-                                               const long long* __restrict__ soff, const unsigned char* __restrict__ isdiag,
-                                               const double* __restrict__ nuk, const double* __restrict__ wk,
-                                               const double* __restrict__ z0, const double* __restrict__ Dinv,
-                                               const double* __restrict__ sigma, double* __restrict__ g,
-                                               const int* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
-                                               double* __restrict__ nus, const double* __restrict__ c, const double* __restrict__ kappa,
-                                               double* __restrict__ p, double* __restrict__ qv) {
-  const double sg = *sigma;
-  if (bid >= nat) {
-    int e = (bid - nat) * kThreads + threadIdx.x;
-    if (e < NE) g[e] = gather_val(e, sptr, soff, isdiag, nuk, wk, z0, Dinv, sg);
-    return;
-  }
-  int j = (bid * kThreads + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (j >= ng) return;
-  double s = 0.0;
-  for (int q = ptr[j] + lane; q < ptr[j + 1]; q += 64) s += val[q] * gather_val(row[q], sptr, soff, isdiag, nuk, wk, z0, Dinv, sg);
-  s = wave_sum(s);
-  if (lane == 0) {
-    double v = nus[j], wv = v > 0.0 ? v : 0.0;
-    double kap = kappa ? *kappa : 1.0;
-    if (kap != 1.0) { v = wv + kap * (v - wv); nus[j] = v; }
-    double pp = 2.0 * wv - v - c[j];
-    p[j] = pp;
-    qv[j] = s - pp;
-  }
-}
-__global__ __launch_bounds__(kThreads) void k_gather_At(int nat, int NE, int ng, const int* __restrict__ sptr,
-                                                         const long long* __restrict__ soff, const unsigned char* __restrict__ isdiag,
-                                                         const double* __restrict__ nuk, const double* __restrict__ wk,
-                                                         const double* __restrict__ z0, const double* __restrict__ Dinv,
-                                                         const double* __restrict__ sigma, double* __restrict__ g,
-                                                         const int* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
-                                                         double* __restrict__ nus, const double* __restrict__ c, const double* __restrict__ kappa,
-                                                         double* __restrict__ p, double* __restrict__ qv) {
-  gather_At_body(blockIdx.x, nat, NE, ng, sptr, soff, isdiag, nuk, wk, z0, Dinv, sigma, g, ptr, row, val, nus, c, kappa, p, qv);
-}
-
-__global__ __launch_bounds__(kThreads) void k_gather_At_b(const IterArgs* __restrict__ A, int nat_max) {
-  const IterArgs a = A[blockIdx.y];
-  // blockIdx.x < nat_max: A' waves of this SDP (nat of them are live); the rest: plain gather blocks
-  const int nat = (int)(((long long)a.ng * 64 + kThreads - 1) / kThreads);
-  int bid = blockIdx.x;
-  if (bid < nat_max) { if (bid >= nat) return; }
-  else {
-    bid = nat + (bid - nat_max);
-    if ((long long)(bid - nat) * kThreads >= (long long)a.NE) return;
-  }
-  gather_At_body(bid, nat, a.NE, a.ng, a.sptr, a.soff, a.isdiag, a.nu + a.ng, a.w + a.ng, a.z0, a.Dinv, a.sigma, a.g,
-                 a.csc_ptr, a.csc_row, a.csc_val, a.nu, a.c, a.kappa, a.p, a.qv);
 }
 
 // ww = Minv qv  (Minv symmetric, column-major): one wave per output row, coalesced column reads
@@ -1736,49 +1647,6 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x_all_b(const IterArgs* __r
   }
 }
 
-// Fused x = g - Dinv A ww  +  the multiplier block of the nu-update (one launch instead of two).  The clique blocks of the
-// update are DEFERRED: the next projection applies them to its own matrix while loading it (ProjArgs.pend / x / gidx);
-// this kernel raises the flag.  blocks [0, nreg) short rows, [nreg, nreg + nlong) long rows, the rest the multipliers.
-__device__ __forceinline__ void Ax_upd_body(const int bid, int NE, int nreg, int nlong, const int* __restrict__ rows,
-                                            const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
-                                            const double* __restrict__ ww, const double* __restrict__ g, const double* __restrict__ Dinv,
-                                            double* __restrict__ x, int ng, const double* __restrict__ p, const double* __restrict__ c,
-                                            double* __restrict__ nu, double alpha, double* __restrict__ kappa, int* __restrict__ pend) {
-  if (bid < nreg) { spmv_A_x_body(bid, NE, ptr, col, val, ww, g, Dinv, x); return; }
-  if (bid < nreg + nlong) { spmv_A_x_long_body(bid - nreg, nlong, rows, ptr, col, val, ww, g, Dinv, x); return; }
-  const int i = (bid - nreg - nlong) * kThreads + threadIdx.x;
-  if (i < ng) {
-    double v = nu[i], wv = v > 0.0 ? v : 0.0;
-    double kxq = p[i] + ww[i] + c[i];
-    double res = kxq - wv;
-    nu[i] = v + alpha * res;
-  }
-  if (i == 0) { if (kappa) *kappa = 1.0; *pend = 1; }
-}
-__global__ __launch_bounds__(kThreads) void k_Ax_upd(int NE, int nreg, int nlong, const int* __restrict__ rows,
-                                                      const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
-                                                      const double* __restrict__ ww, const double* __restrict__ g, const double* __restrict__ Dinv,
-                                                      double* __restrict__ x, int ng, const double* __restrict__ p, const double* __restrict__ c,
-                                                      double* __restrict__ nu, double alpha, double* __restrict__ kappa, int* __restrict__ pend) {
-  Ax_upd_body(blockIdx.x, NE, nreg, nlong, rows, ptr, col, val, ww, g, Dinv, x, ng, p, c, nu, alpha, kappa, pend);
-}
-
-__global__ __launch_bounds__(kThreads) void k_Ax_upd_b(const IterArgs* __restrict__ A, int nreg_max, int nlong_max) {
-  const IterArgs a = A[blockIdx.y];
-  const int nreg = (int)(((long long)a.NE * kRowLanes + kThreads - 1) / kThreads);
-  int bid = blockIdx.x;
-  if (bid < nreg_max) { if (bid >= nreg) return; }
-  else if (bid < nreg_max + nlong_max) {
-    if (bid - nreg_max >= a.nlong) return;
-    bid = nreg + (bid - nreg_max);
-  } else {
-    bid = nreg + a.nlong + (bid - nreg_max - nlong_max);
-    if ((long long)(bid - nreg - a.nlong) * kThreads >= (long long)a.ng) return;
-  }
-  Ax_upd_body(bid, a.NE, nreg, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x, a.ng, a.p, a.c, a.nu,
-              a.alpha, a.kappa, a.pend);
-}
-
 // nu <- nu + alpha (K x + q - w).  acc (may be null) accumulates at check iterations:
 //   acc[0] += |Kx+q-w|^2, acc[1] += |Kx+q|^2, acc[2] += |w|^2
 __device__ __forceinline__ void update_nu_body(const int bid, int ng, long long nmat, const double* __restrict__ p,
@@ -1786,7 +1654,7 @@ __device__ __forceinline__ void update_nu_body(const int bid, int ng, long long 
                                                          const double* __restrict__ x, const unsigned int* __restrict__ gidx,
                                                          double* __restrict__ nu, const double* __restrict__ w,
                                                          double alpha, double* __restrict__ kappa, double* __restrict__ acc,
-                                                         long long lo, long long hi, int acc_s, int* __restrict__ pend = nullptr) {
+                                                         long long lo, long long hi, int acc_s) {
   // [lo, hi): the clique elements this rank owns (everything when not sharded); acc_s: count the
   // multiplier block in the residual sums (rank 0 only when sharded, the sums are all-reduced)
   __shared__ double red[8];
@@ -1815,18 +1683,17 @@ __device__ __forceinline__ void update_nu_body(const int bid, int ng, long long 
     if (threadIdx.x == 0) { atomicAdd(&acc[0], r2); atomicAdd(&acc[1], k2); atomicAdd(&acc[2], w2); }
   }
   if (i == 0 && kappa) *kappa = 1.0;
-  if (i == 0 && pend) *pend = 0;     // a complete update: nothing is left for the next projection to apply
 }
 __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, const double* __restrict__ p,
                                                          const double* __restrict__ ww, const double* __restrict__ c,
                                                          const double* __restrict__ x, const unsigned int* __restrict__ gidx,
                                                          double* __restrict__ nu, const double* __restrict__ w,
                                                          double alpha, double* __restrict__ kappa, double* __restrict__ acc,
-                                                         long long lo, long long hi, int acc_s, int* __restrict__ pend) { update_nu_body(blockIdx.x, ng, nmat, p, ww, c, x, gidx, nu, w, alpha, kappa, acc, lo, hi, acc_s, pend); }
+                                                         long long lo, long long hi, int acc_s) { update_nu_body(blockIdx.x, ng, nmat, p, ww, c, x, gidx, nu, w, alpha, kappa, acc, lo, hi, acc_s); }
 __global__ __launch_bounds__(kThreads) void k_update_nu_b(const IterArgs* __restrict__ A) {
   const IterArgs a = A[blockIdx.y];
   if ((long long)blockIdx.x * kThreads >= (long long)a.ng + a.nmat) return;
-  update_nu_body(blockIdx.x, a.ng, a.nmat, a.p, a.ww, a.c, a.x, a.gidx, a.nu, a.w, a.alpha, a.kappa, nullptr, 0LL, a.nmat, 1, a.pend);
+  update_nu_body(blockIdx.x, a.ng, a.nmat, a.p, a.ww, a.c, a.x, a.gidx, a.nu, a.w, a.alpha, a.kappa, nullptr, 0LL, a.nmat, 1);
 }
 
 // check iteration, dual side: t[e] = (K'y)[e] = sum_g A[e,g] ys[g] + wgt * sum_src y_k[src],
