@@ -19,7 +19,8 @@ torch.distributed.run, one rank per GPU.  One JSON line on rank 0.
              vector/matrix peak; achieved = algorithmic flops (10 * sum n_k^3 of the blocks solved)
              / average kernel duration from HIP events recorded on the solver's stream inside the
              timed region.  The HBM-side figures the north star asks for are reported as hbm_*.
-  * cpu_baseline: the numpy oracle (same ADMM, LAPACK eigh) timed on the host for a bounded sample.
+  * cpu_baseline: the C++/OpenMP port of the same ADMM iteration (oracle/c, LAPACK dsyevd per clique) timed on the host
+             cores for a bounded sample, plus its estimated time to the certificates the GPU solves reached.
 """
 import argparse
 import json
@@ -42,36 +43,55 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = fp64 matrix peak (half the f
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(workload: str, beta: int, seconds: float):
-    """oracle ADMM (numpy, LAPACK eigh per clique) timed on the host cores: a reported baseline."""
+def cpu_baseline(workload: str, beta: int, seconds: float, gpu_iters_to_cert=None):
+    """Same-box CPU restatement: the oracle's ADMM iteration in C++ / OpenMP with LAPACK dsyevd per
+    clique (oracle/c/admm_cpu.cpp, one thread per clique) on the host cores - a reported baseline, not the target.  The
+    reference's own CPU path (Julia + MOSEK) cannot run here.  Falls back to the numpy oracle if the C++ port is not built."""
     import helpers
     from oracle import operator as oop, admm as oadmm
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
     cores = min(16, os.cpu_count() or 1)
     d = helpers.load_problem(workload, beta)
     q = helpers.oracle_query(d)
+    out = {"unit": "ADMM iters/s", "cores": cores, "kind": "port"}
+    try:
+        from oracle import admm_c
+        rates = {}
+        for mode in ("single", "double"):
+            P = oadmm.ScaledProblem(oop.build_operator(q, mode, normalize=True))
+            S = admm_c.CpuAdmm(P, 0.1, 1.6, threads=cores)
+            S.step(3)
+            n, t0 = 0, time.time()
+            budget = seconds * (0.7 if mode == "single" else 0.3)
+            while time.time() - t0 < budget:
+                S.step(10)
+                n += 10
+            rates[mode] = (n, time.time() - t0)
+        n, dt = rates["single"]
+        out.update(value=n / dt, sample=f"{n} iterations of the C++/OpenMP port of the ADMM iteration (oracle/c/admm_cpu.cpp: LAPACK dsyevd per clique, "
+                                        f"{cores} threads, explicit M^-1 as on the GPU) on {workload} beta={beta}, Single decomposition, in {dt:.1f} s")
+        n2, dt2 = rates["double"]
+        out["double_decomp_iters_per_s"] = n2 / dt2
+        if gpu_iters_to_cert:
+            # the port runs the very iteration of the GPU solver (iterates agree to 1e-13, tests/test_cpu_port.py), so its
+            # time to the same certificate is the GPU's iteration count over the CPU rate
+            out["time_to_cert_estimate_s"] = {k: v / (n2 / dt2) for k, v in gpu_iters_to_cert.items()}
+            out["time_to_cert_note"] = ("Double decomposition; iterations the GPU solve needed (same iteration, same stopping rule) divided by the "
+                                        "measured CPU rate: an estimate, the full CPU solve is not run inside the benchmark")
+        return out
+    except Exception as e:      # C++ port not built: numpy oracle
+        out["port_error"] = repr(e)
     L = oop.build_operator(q, "single", normalize=True)
-
-    def run():
-        P = oadmm.ScaledProblem(L)
-        S = oadmm.AdmmState(P, 0.1, 1.6)
-        for _ in range(3):
-            S.step()
-        n, t0 = 0, time.time()
-        while time.time() - t0 < seconds:
-            S.step()
-            n += 1
-        return n, time.time() - t0
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=cores):
-            n, dt = run()
-    else:
-        n, dt = run()
-    return {"value": n / dt, "unit": "ADMM iters/s", "cores": cores, "kind": "port",
-            "sample": f"{n} iterations of the numpy oracle ADMM (oracle/admm.py, LAPACK eigh per clique) on {workload} beta={beta} in {dt:.1f} s"}
+    P = oadmm.ScaledProblem(L)
+    S = oadmm.AdmmState(P, 0.1, 1.6)
+    for _ in range(3):
+        S.step()
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        S.step()
+        n += 1
+    dt = time.time() - t0
+    out.update(value=n / dt, sample=f"{n} iterations of the numpy oracle ADMM (oracle/admm.py, LAPACK eigh per clique) on {workload} beta={beta} in {dt:.1f} s")
+    return out
 
 
 def main():
@@ -178,16 +198,22 @@ def main():
 
     out = None
     if rank == 0:
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_counters_W40-D20.json")))
-            kj = [v for k, v in pmc.items() if "k_proj_jacobi" in k][0]
-            # FETCH_SIZE / WRITE_SIZE are KB; gfx950 FETCH_SIZE under-reports wide streaming reads by 2x
-            # (MI355X_MICROARCH.md, HBM section); our loads are 8 B/lane, for which the guide gives no calibration,
-            # so the corrected value is an upper bound
-            traffic = (2.0 * kj["FETCH_SIZE"]["mean_per_launch"] + kj["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-        except Exception:
-            traffic = None
+        # HBM bytes of the projection kernel per launch from the PMC counters: these need their own rocprofv3 --pmc passes
+        # (tools/collect_profiles.sh), so the figure is read from the committed summary of the SAME workload and build round
+        # and labelled as such; absent or for another workload it stays null
+        traffic, traffic_source = None, None
+        pmc_file = os.path.join(ROOT, "profiles", f"r02_pmc_counters_{args.workload}.json")
+        if args.beta == 0 and os.path.exists(pmc_file):
+            try:
+                pmc = json.load(open(pmc_file))
+                kj = [v for k, v in pmc.items() if "k_proj_jacobi" in k][0]
+                # FETCH_SIZE / WRITE_SIZE are KB; gfx950 FETCH_SIZE under-reports wide streaming reads by 2x
+                # (MI355X_MICROARCH.md, HBM section); our loads are 8 B/lane, for which the guide gives no calibration,
+                # so the corrected value is an upper bound
+                traffic = (2.0 * kj["FETCH_SIZE"]["mean_per_launch"] + kj["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+                traffic_source = f"profiles/{os.path.basename(pmc_file)} (separate rocprofv3 --pmc passes of this command, offline)"
+            except Exception:
+                traffic = None
         eig_avg_s = eig_ms * 1e-3 / args.steps
         flops = float(sm["eig_flops_per_iter"])
         byts = float(sm["eig_bytes_per_iter"])
@@ -210,7 +236,7 @@ def main():
                                                              else f"; {world} independent SDPs, one per GPU")),
                        "parallelism": ("clique-sharded, 1 all-reduce/iteration" if shard else "1 SDP per GPU, cliques batched in one launch")},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_proj_jacobi", "kernel_avg_us": eig_avg_s * 1e6,
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
                          "hbm_achieved_GBs": byts / eig_avg_s / 1e9, "hbm_frac": byts / eig_avg_s / 1e9 / HBM_PEAK_GBS},
@@ -258,7 +284,10 @@ def main():
                           "note": "independent SDPs (beta sweep of experiments/scale.jl:28, hyperplanes of findReach2Dpoly, ACAS sub-queries) in lockstep on one GPU, "
                                   "nnsdp_batch_*: one launch per stage for all SDPs, hipGraph replay; 13 x 19 blocks = 247 of the 256 CUs"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds)
+        need = None
+        if "time_to_cert" in out:
+            need = {k.split("/")[1]: v["iters"] for k, v in out["time_to_cert"].items() if isinstance(v, dict) and k.startswith("DoubleDecomp/")}
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.beta, args.cpu_seconds, need)
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:

@@ -3,7 +3,7 @@
 # aggregated into gpurun_out/profiles_new/ (copy into profiles/ afterwards).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -52,9 +52,16 @@ if k:
     print("k_proj_jacobi per launch: FETCH_SIZE KB", f, "WRITE_SIZE KB", w, "LDS conflict share",
           k.get("SQ_LDS_BANK_CONFLICT", {}).get("mean_per_launch", 0) / max(k.get("SQ_LDS_IDX_ACTIVE", {}).get("mean_per_launch", 1), 1))
 PY
-# batched regime (batch handle, 13 SDPs in lockstep); eager launches: rocprofv3 crashes on graph capture with many handles
+# batched regime (batch handle, 13 SDPs in lockstep), hipGraph replay ON.  rocprofv3 --kernel-trace segfaults inside the
+# profiler when a process replays graphs of many solver handles (r01 worked around it with NNSDP_NO_GRAPH=1): the HIP runtime's
+# graph packet capture pre-builds the AQL packets with device-resident kernel arguments, and the tool dereferences that address
+# on the host (stack: hipGraphLaunch -> rocprofiler-sdk queue interception -> memcpy, SIGSEGV at a device VA).  Nothing in the
+# library's capture is at fault (one stream, no events, no cross-stream work inside it); turning the runtime feature off for the
+# profiled run lets the same graphs replay through the ordinary dispatch path.
 cd /tmp
-NNSDP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bstats -- python3 $R/tools/batch_bench.py 13 W40-D20 400 > $OUT/${TAG}_batched13_W40-D20.log 2> $OUT/bstats.err || true
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bstats -- python3 $R/tools/batch_bench.py 13 W40-D20 400 > $OUT/${TAG}_batched13_W40-D20.log 2> $OUT/bstats.err
+unset DEBUG_CLR_GRAPH_PACKET_CAPTURE
 cd $R
 for f in $OUT/bstats/*/*kernel_stats.csv; do cp $f $OUT/${TAG}_batched13_W40-D20_kernel_stats.csv; done
 rm -rf $OUT/stats $OUT/pmc_* $OUT/bstats   # raw traces are large; only the aggregates travel back
