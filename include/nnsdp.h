@@ -94,6 +94,10 @@ typedef struct nnsdp_options {
                              boxes of collapsed deep nets are narrower than their own rounding error and, taken
                              literally, make the QC set empty (rho = 0 would be "optimal"); MOSEK at 1e-6 never
                              resolves that, an exact solver does. */
+  int32_t minv_mode;      /* the Woodbury core M^-1, M = I + A'D^-1A over the kept multipliers: 1 = dense inverse (8 ng^2 bytes read
+                             per iteration), 2 = structured (block-banded by network layer + low rank: two-level domain
+                             decomposition, three launches, O(ng b) bytes), 0 = auto (structured from 3500 kept multipliers on,
+                             when the generator table has that structure) */
 } nnsdp_options;
 
 /* Contents of Methods.QuerySolution (src/Methods/Methods.jl:46-55) plus solver diagnostics.
@@ -153,6 +157,9 @@ int nnsdp_solver_iterate_async(nnsdp_solver* s, int32_t iters);
 int nnsdp_solver_sync(nnsdp_solver* s);
 /* relative residuals and objectives of the current iterate */
 int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* pobj, double* dobj);
+/* test / diagnostic entry: out = M^-1 q for a full-length multiplier vector q (entries of dropped multipliers are ignored and
+ * returned as 0), through whichever form the handle uses; *structured (may be NULL) tells which, *operand_bytes its size */
+int nnsdp_solver_apply_minv(nnsdp_solver* s, const double* q, double* out, int32_t* structured, int64_t* operand_bytes);
 /* iterate until converged / limits; fills r like nnsdp_solve */
 int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r);
 int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r);

@@ -30,6 +30,7 @@ struct PathDecomp <: DecompMode end
   verbose::Bool = false
   device::Int = -1
   interval_guard::Float64 = 5e-5
+  minv_mode::Int = 0
 end
 
 # field order and types must match include/nnsdp.h
@@ -44,7 +45,7 @@ end
 struct COptions
   decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
   adapt_every::Int32; check_every::Int32; normalize::Int32; warm_start::Int32; proj_tol::Float64
-  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32; interval_guard::Float64
+  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32; interval_guard::Float64; minv_mode::Int32
 end
 mutable struct CResult
   gamma_in::Ptr{Float64}; gamma_out::Ptr{Float64}; gamma_ac1::Ptr{Float64}; gamma_ac2::Ptr{Float64}; Z::Ptr{Float64}
@@ -87,7 +88,7 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
     f1 > f0 || error("obj_func must be increasing in γout[1]")
   end
   copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
-                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device, opts.interval_guard)
+                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device, opts.interval_guard, opts.minv_mode)
   res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
                 0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0)
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin

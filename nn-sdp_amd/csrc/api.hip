@@ -16,6 +16,7 @@
 #include "../../include/nnsdp.h"
 #include "kernels.hip"
 #include "setup.hpp"
+#include "minv.hpp"
 #include "intervals.hpp"
 
 namespace nnsdp {
@@ -286,6 +287,13 @@ struct nnsdp_solver {
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
   DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc, gs;
+  // structured M^-1 (minv.hpp): used instead of the dense inverse for large multiplier counts
+  bool minv_structured = false;
+  MinvPlan mplan;
+  MinvDev mdev{};
+  DBuf<int> m_clo, m_chi, m_w0, m_w1, m_hslot0, m_chunk_of, m_sep_of, m_sep_gen, m_slot_chunk, m_slotA, m_slotB;
+  DBuf<long long> m_poff, m_hoff;
+  DBuf<double> m_P, m_H, m_HT, m_Sc, m_v, m_kap, m_t, m_rpart, m_xS, m_coef;
   DBuf<double> symv_part;   // batch handles: partial products of the tiled symmetric M^-1 q
   double sigma = 1.0, proj_tol = 1e-4;
   hipStream_t st = nullptr;
@@ -344,7 +352,10 @@ struct nnsdp_solver {
         throw std::invalid_argument(std::string("PATH decomposition needs an output QC without x_1 -- x_K coupling (S12 = 0): ") + e.what());
       throw;
     }
-    S = scale_operator(op, opt.normalize != 0);
+    {
+      std::vector<int> layers = P.generator_layers();
+      S = scale_operator(op, opt.normalize != 0, &layers);     // multipliers ordered by network layer (any order is the same iteration)
+    }
     pat = std::move(op.pat);
     D.upload(S, pat);
     ncl = (int)pat.cliques.size();
@@ -420,14 +431,20 @@ struct nnsdp_solver {
     RBCHK(rocblas_set_stream(roc->h, st));
     int ng = S.ng;
     ldm = (ng + 1) & ~1;
-    {
+    if (opt.minv_mode < 0 || opt.minv_mode > 2) throw std::invalid_argument("minv_mode must be 0 (auto), 1 (dense) or 2 (structured)");
+    if (opt.minv_mode == 2 || (opt.minv_mode == 0 && ng >= kStructuredMinvFrom)) {
+      mplan = plan_minv(S);
+      if (mplan.ok) minv_structured = true;
+      else if (opt.minv_mode == 2) throw std::invalid_argument("structured M^-1 not applicable: too few layers or the generator table is not block-banded by layer");
+    }
+    if (minv_structured) build_structured_minv();
+    else {
       std::vector<double> M;
       build_M(S, M);
       Minv.alloc((size_t)ldm * std::max(ng, 1));
       Minv.zero();
       HIPCHK(hipMemcpy2D(Minv.p, (size_t)ldm * sizeof(double), M.data(), (size_t)ng * sizeof(double), (size_t)ng * sizeof(double),
                          ng, hipMemcpyHostToDevice));
-    }
     DBuf<rocblas_int> info;
     info.alloc(1);
     RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
@@ -437,6 +454,7 @@ struct nnsdp_solver {
     hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(ng, 256), ng), dim3(256), 0, st, ng, ldm, Minv.p);
     HIPCHK(hipStreamSynchronize(st));
     if (info.download()[0] != 0) throw HipError("inverse of M = I + A'D^-1A failed (potri info != 0)");
+    }
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
     x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
@@ -454,6 +472,110 @@ struct nnsdp_solver {
     if (lds_bytes > 64 * 1024) HIPCHK(proj_allow_big_lds());
     k0 = 0; k1 = ncl;
     t_setup = now_s() - t_create0;
+  }
+
+  static constexpr int kStructuredMinvFrom = 3500;   // auto mode: kept multipliers from which the structured M^-1 replaces the dense one (98 MB)
+
+  // device set-up of the structured M^-1 (minv.hpp): small dense inverses through rocSOLVER / rocBLAS, all on the solver's stream
+  void build_structured_minv() {
+    const MinvPlan& Q = mplan;
+    MinvBlocks B = assemble_minv_blocks(S, Q);
+    const int ng = S.ng, nc = Q.nchunk, nS = Q.nS;
+    DBuf<double> Tjs;
+    m_P.upload(B.Tjj); Tjs.upload(B.Tjs); m_Sc.upload(B.Tss);
+    m_H.alloc((size_t)Q.htot); m_HT.alloc((size_t)Q.htot);
+    DBuf<rocblas_int> info;
+    info.alloc(1);
+    const double one = 1.0, zero = 0.0, mone = -1.0;
+    for (int j = 0; j < nc; ++j) {
+      const int n = Q.chi[j] - Q.clo[j], wj = Q.w1[j] - Q.w0[j];
+      double* Pj = m_P.p + Q.poff[j];
+      RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, n, Pj, n, info.p));
+      HIPCHK(hipStreamSynchronize(st));
+      if (info.download()[0] != 0) throw HipError("structured M^-1: Cholesky of a chunk block failed");
+      RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, n, Pj, n, info.p));
+      hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, n, Pj);
+      if (wj > 0) {
+        double* Hj = m_H.p + Q.hoff[j];
+        const double* Tj = Tjs.p + Q.hoff[j];
+        RBCHK(rocblas_dgemm(roc->h, rocblas_operation_none, rocblas_operation_none, n, wj, n, &one, Pj, n, Tj, n, &zero, Hj, n));
+        RBCHK(rocblas_dgemm(roc->h, rocblas_operation_transpose, rocblas_operation_none, wj, wj, n, &mone, Tj, n, Hj, n, &one,
+                            m_Sc.p + (size_t)Q.w0[j] * nS + Q.w0[j], nS));
+        hipLaunchKernelGGL(k_minv_transpose, dim3(cdiv((long long)n * wj, 256)), dim3(256), 0, st, n, wj, Hj, m_HT.p + Q.hoff[j]);
+      }
+    }
+    RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, nS, m_Sc.p, nS, info.p));
+    HIPCHK(hipStreamSynchronize(st));
+    if (info.download()[0] != 0) throw HipError("structured M^-1: Cholesky of the separator Schur complement failed");
+    RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, nS, m_Sc.p, nS, info.p));
+    hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(nS, 256), nS), dim3(256), 0, st, nS, nS, m_Sc.p);
+    // index maps
+    std::vector<int> sep_gen(nS), hslot0(nc), slot_chunk, slotA(nS), slotB(nS);
+    for (int g = 0; g < ng; ++g) if (Q.sep_of[g] >= 0) sep_gen[Q.sep_of[g]] = g;
+    int nslots = 0;
+    for (int j = 0; j < nc; ++j) { hslot0[j] = nslots; for (int c = Q.w0[j]; c < Q.w1[j]; ++c) slot_chunk.push_back(j); nslots += Q.w1[j] - Q.w0[j]; }
+    for (int sj = 0; sj + 1 < nc; ++sj)
+      for (int c = Q.soff[sj]; c < Q.soff[sj + 1]; ++c) { slotA[c] = hslot0[sj] + (c - Q.w0[sj]); slotB[c] = hslot0[sj + 1] + (c - Q.w0[sj + 1]); }
+    m_clo.upload(Q.clo); m_chi.upload(Q.chi); m_w0.upload(Q.w0); m_w1.upload(Q.w1); m_hslot0.upload(hslot0);
+    m_poff.upload(Q.poff); m_hoff.upload(Q.hoff); m_chunk_of.upload(Q.chunk_of); m_sep_of.upload(Q.sep_of);
+    m_sep_gen.upload(sep_gen); m_slot_chunk.upload(slot_chunk); m_slotA.upload(slotA); m_slotB.upload(slotB);
+    m_t.alloc(ng); m_rpart.alloc(std::max(nslots, 1)); m_xS.alloc(std::max(nS, 1)); m_coef.alloc(8);
+    m_v.alloc((size_t)ng * std::max(Q.r, 1)); m_kap.alloc(64);
+    m_v.zero(); m_kap.zero(); m_coef.zero();
+    mdev.ng = ng; mdev.nchunk = nc; mdev.nS = nS; mdev.r = 0; mdev.nslots = nslots;
+    mdev.clo = m_clo.p; mdev.chi = m_chi.p; mdev.w0 = m_w0.p; mdev.w1 = m_w1.p; mdev.hslot0 = m_hslot0.p;
+    mdev.poff = m_poff.p; mdev.hoff = m_hoff.p; mdev.chunk_of = m_chunk_of.p; mdev.sep_of = m_sep_of.p; mdev.sep_gen = m_sep_gen.p;
+    mdev.slot_chunk = m_slot_chunk.p; mdev.slotA = m_slotA.p; mdev.slotB = m_slotB.p;
+    mdev.Pinv = m_P.p; mdev.H = m_H.p; mdev.HT = m_HT.p; mdev.Scinv = m_Sc.p; mdev.v = m_v.p; mdev.kap = m_kap.p;
+    mdev.t = m_t.p; mdev.rpart = m_rpart.p; mdev.xS = m_xS.p; mdev.coef = m_coef.p;
+    // low-rank part: v = T^-1 U (the structured apply with r = 0), kap = (diag(1/d) + U'v)^-1 on the host (r x r, r <= 8)
+    if (Q.r > 0) {
+      DBuf<double> U, V;
+      U.upload(B.U);
+      V.alloc((size_t)ng * Q.r);
+      for (int a = 0; a < Q.r; ++a) apply_structured_minv(U.p + (size_t)a * ng, V.p + (size_t)a * ng, st);
+      HIPCHK(hipStreamSynchronize(st));
+      std::vector<double> vh = V.download();
+      std::vector<double> Km((size_t)Q.r * Q.r, 0.0);
+      for (int a = 0; a < Q.r; ++a)
+        for (int b = 0; b < Q.r; ++b) {
+          double sdot = a == b ? 1.0 / B.dU[a] : 0.0;
+          for (int g = 0; g < ng; ++g) sdot += B.U[(size_t)a * ng + g] * vh[(size_t)b * ng + g];
+          Km[(size_t)a * Q.r + b] = sdot;
+        }
+      // Gauss-Jordan inverse of the small symmetric positive definite matrix
+      const int r = Q.r;
+      std::vector<double> Ki((size_t)r * r, 0.0);
+      for (int a = 0; a < r; ++a) Ki[(size_t)a * r + a] = 1.0;
+      for (int cidx = 0; cidx < r; ++cidx) {
+        const double pv = Km[(size_t)cidx * r + cidx];
+        if (!(pv > 0.0)) throw HipError("structured M^-1: low-rank capacitance matrix is not positive definite");
+        for (int b = 0; b < r; ++b) { Km[(size_t)cidx * r + b] /= pv; Ki[(size_t)cidx * r + b] /= pv; }
+        for (int a = 0; a < r; ++a) {
+          if (a == cidx) continue;
+          const double f = Km[(size_t)a * r + cidx];
+          for (int b = 0; b < r; ++b) { Km[(size_t)a * r + b] -= f * Km[(size_t)cidx * r + b]; Ki[(size_t)a * r + b] -= f * Ki[(size_t)cidx * r + b]; }
+        }
+      }
+      HIPCHK(hipMemcpy(m_v.p, vh.data(), vh.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(m_kap.p, Ki.data(), Ki.size() * sizeof(double), hipMemcpyHostToDevice));
+      mdev.r = r;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+  }
+
+  // out = M^-1 q through the structured form: three dependent launches
+  void apply_structured_minv(const double* q, double* out, hipStream_t s_) {
+    const int ng = S.ng;
+    hipLaunchKernelGGL(k_minv_stage1, dim3(cdiv((long long)(ng + mdev.nslots) * 64, kThreads)), dim3(kThreads), 0, s_, mdev, q);
+    hipLaunchKernelGGL(k_minv_stage2, dim3(cdiv((long long)mdev.nS * 64, kThreads) + 1), dim3(kThreads), 0, s_, mdev, q);
+    hipLaunchKernelGGL(k_minv_stage3, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, s_, mdev, out);
+  }
+
+  // ww = M^-1 qv on stream s_ (dense GEMV or the structured form)
+  void enqueue_minv(hipStream_t s_) {
+    if (minv_structured) apply_structured_minv(qv.p, ww.p, s_);
+    else hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)S.ng * 64, kThreads)), dim3(kThreads), 0, s_, S.ng, ldm, Minv.p, qv.p, ww.p);
   }
 
   void set_comm(int nr, int rk, const char* id128) {
@@ -545,7 +667,7 @@ struct nnsdp_solver {
                          D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p,
                          comm ? hsum.p : (const double*)nullptr);
     }
-    hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, ldm, Minv.p, qv.p, ww.p);
+    enqueue_minv(st);
     {
       const int nreg = cdiv((long long)NE * kRowLanes, kThreads);
       hipLaunchKernelGGL(k_spmv_A_x_all, dim3(nreg + nlong), dim3(kThreads), 0, st, NE, nreg, nlong, d_long.p, D.csr_ptr.p, D.csr_col.p,
@@ -994,7 +1116,7 @@ struct nnsdp_batch {
   DBuf<ProjArgs> d_pw, d_pc;           // warm / cold projection arguments
   DBuf<int2> d_map;
   int nblocks = 0, nmax = 0, alg = 0;
-  bool v_lds = true;
+  bool v_lds = true, any_structured = false;
   size_t lds = 0;
   int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
   hipGraph_t graph = nullptr;
@@ -1033,8 +1155,10 @@ struct nnsdp_batch {
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
     nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = 0;
+    any_structured = false;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
+      any_structured = any_structured || s->minv_structured;
       HIPCHK(hipStreamSynchronize(s->st));
       s->since_cold = nnsdp_solver::kColdPeriod;   // lockstep: the next batched iteration is a cold one for everybody
       IterArgs a;
@@ -1048,7 +1172,7 @@ struct nnsdp_batch {
       a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
       {
         const size_t nb = (size_t)(a.ng + 63) / 64;
-        if (s->symv_part.n != nb * nb * 64) s->symv_part.alloc(nb * nb * 64);
+        if (!s->minv_structured && s->symv_part.n != nb * nb * 64) s->symv_part.alloc(nb * nb * 64);
         a.symv_part = s->symv_part.p;
         gx_tiles = std::max(gx_tiles, cdiv((long long)(nb * (nb + 1) / 2), kThreads / 64));
         gx_nb = std::max(gx_nb, (int)nb);
@@ -1084,7 +1208,8 @@ struct nnsdp_batch {
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
     static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic
-    if (full_gemv) hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
+    if (any_structured) { for (nnsdp_solver* s : act) s->enqueue_minv(st); }     // large multiplier counts: each SDP's structured M^-1
+    else if (full_gemv) hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);
     else {
       hipLaunchKernelGGL(k_symv_tiles_b, dim3(gx_tiles, B), dim3(kThreads), 0, st, d_it.p);
       hipLaunchKernelGGL(k_symv_reduce_b, dim3(gx_nb, B), dim3(64), 0, st, d_it.p);
@@ -1193,6 +1318,7 @@ void nnsdp_default_options(nnsdp_options* o) {
   o->verbose = 0;
   o->device = -1;
   o->interval_guard = 5e-5;
+  o->minv_mode = 0;
 }
 
 int nnsdp_problem_dims(const nnsdp_problem* p, int32_t* Zdim, int32_t* acdim, int32_t* nac2, int32_t* ngamma) {
@@ -1262,6 +1388,26 @@ int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* 
   if (dres) *dres = s->last_dres;
   if (pobj) *pobj = s->last_pobj;
   if (dobj) *dobj = s->last_dobj;
+  API_END
+}
+
+int nnsdp_solver_apply_minv(nnsdp_solver* s, const double* q, double* out, int32_t* structured, int64_t* operand_bytes) {
+  API_BEGIN
+  if (!s || !q || !out) throw std::invalid_argument("null argument");
+  const int ng = s->S.ng;
+  std::vector<double> qk(ng);
+  for (int g = 0; g < ng; ++g) qk[g] = q[s->S.keep[g]];
+  HIPCHK(hipMemcpy(s->qv.p, qk.data(), ng * sizeof(double), hipMemcpyHostToDevice));
+  s->enqueue_minv(s->st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s->st));
+  std::vector<double> o = s->ww.download();
+  for (int g = 0; g < s->P.ng; ++g) out[g] = 0.0;
+  for (int g = 0; g < ng; ++g) out[s->S.keep[g]] = o[g];
+  if (structured) *structured = s->minv_structured ? 1 : 0;
+  if (operand_bytes)
+    *operand_bytes = s->minv_structured ? (int64_t)((s->m_P.n + s->m_H.n + s->m_HT.n + s->m_Sc.n + s->m_v.n) * sizeof(double))
+                                        : (int64_t)(s->Minv.n * sizeof(double));
   API_END
 }
 

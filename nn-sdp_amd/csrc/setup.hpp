@@ -37,6 +37,22 @@ struct ProblemCopy {
   std::vector<double> x1min, x1max, acymin, acymax, smin, smax, normal, yc, invP, S;
   int Zdim = 0, acdim = 0, nin = 0, nout = 0, n1 = 0, npairs = 0, n2 = 0, ng = 0, mout = 0;
   std::vector<int> offs;  // z-offset of block k (size K+1, offs[K] = a = Zdim-1)
+  std::vector<int> neuron_layer;   // hidden layer (0-based) of every neuron t
+
+  // network layer (0-based hidden layer) every multiplier belongs to: generators of layer k touch only the blocks of x_k,
+  // x_{k+1} (and the affine index); a repeated-nonlinearity pair counts for its later neuron
+  std::vector<int> generator_layers() const {
+    std::vector<int> L(ng, 0);
+    const int o1 = nin + nout, ol = o1 + n1, ov = ol + acdim, oe = ov + npairs, on = oe + acdim;
+    for (int t = 0; t < acdim; ++t) {
+      L[o1 + t] = L[ol + t] = neuron_layer[t];
+      if (activ == NNSDP_ACTIV_RELU) L[oe + t] = L[on + t] = neuron_layer[t];
+    }
+    int r = 0;
+    for (int i = 0; i < acdim - 1; ++i)
+      for (int j = i + 1; j < acdim && j - i <= beta; ++j, ++r) L[ov + r] = neuron_layer[j];
+    return L;
+  }
 
   void load(const nnsdp_problem* p) {
     if (!p || !p->xdims || !p->M) throw std::invalid_argument("null problem / xdims / M");
@@ -112,6 +128,9 @@ struct ProblemCopy {
       S.assign(p->S, p->S + (size_t)sd * sd);
     } else throw std::invalid_argument("unrecognized query_kind");
     n1 = acdim;
+    neuron_layer.clear();
+    for (int k = 1; k < K; ++k)
+      for (int i = 0; i < xdims[k]; ++i) neuron_layer.push_back(k - 1);
     // lambda_dim = sum((acdim-beta):acdim) (activ_sector.jl:18) = acdim + #pairs
     npairs = beta * acdim - beta * (beta + 1) / 2;
     n2 = acdim + npairs + (activ == NNSDP_ACTIV_RELU ? 2 * acdim : 0);   // vardim (activ_sector.jl:19)
@@ -473,6 +492,7 @@ class OperatorBuilder {
 struct ScaledOperator {
   int NE = 0, ng = 0, ng_full = 0;
   std::vector<int> keep;            // kept generator -> full index
+  std::vector<int> layer;           // (when ordered by layer) network layer of every kept generator, nondecreasing
   std::vector<double> ecol;         // g_full = ecol * g_scaled / zscale
   double zscale = 1.0, cscale = 1.0;
   std::vector<double> z0, c, Dinv;
@@ -482,7 +502,9 @@ struct ScaledOperator {
   std::vector<double> csc_val;
 };
 
-inline ScaledOperator scale_operator(const Operator& op, bool normalize_columns) {
+// `layer_of` (optional, per full generator index): kept generators are ordered by it (stable), so that the multipliers of one
+// network layer are contiguous - the order the structured M^-1 (minv.hpp) works in.  Any order gives the same iteration.
+inline ScaledOperator scale_operator(const Operator& op, bool normalize_columns, const std::vector<int>* layer_of = nullptr) {
   ScaledOperator S;
   S.NE = op.pat.NE;
   S.ng_full = op.ng;
@@ -491,11 +513,14 @@ inline ScaledOperator scale_operator(const Operator& op, bool normalize_columns)
   std::vector<int> newgen(op.ng, -1);
   for (int g = 0; g < op.ng; ++g) {
     cn[g] = std::sqrt(cn[g]);
-    if (cn[g] > 1e-150) {   // only identically-zero generators are dropped; tiny-width neurons keep theirs
-      newgen[g] = (int)S.keep.size();
-      S.keep.push_back(g);
-      S.ecol.push_back(normalize_columns ? 1.0 / cn[g] : 1.0);
-    }
+    if (cn[g] > 1e-150) S.keep.push_back(g);   // only identically-zero generators are dropped; tiny-width neurons keep theirs
+  }
+  if (layer_of) std::stable_sort(S.keep.begin(), S.keep.end(), [&](int a, int b) { return (*layer_of)[a] < (*layer_of)[b]; });
+  for (size_t i = 0; i < S.keep.size(); ++i) {
+    const int g = S.keep[i];
+    newgen[g] = (int)i;
+    S.ecol.push_back(normalize_columns ? 1.0 / cn[g] : 1.0);
+    if (layer_of) S.layer.push_back((*layer_of)[g]);
   }
   S.ng = (int)S.keep.size();
   double zn = 0, cnrm = 0;
@@ -531,6 +556,17 @@ inline ScaledOperator scale_operator(const Operator& op, bool normalize_columns)
       S.csr_col[k] = g;
       S.csr_val[k] = t.val * S.ecol[g];
       S.csc_ptr[g + 1]++;
+    }
+  }
+  if (layer_of) {
+    // the kept order is a permutation of the full order: re-sort every row by kept index (build_M relies on sorted columns)
+    std::vector<std::pair<int, double>> tmp;
+    for (int e = 0; e < S.NE; ++e) {
+      const int lo = S.csr_ptr[e], hi = S.csr_ptr[e + 1];
+      tmp.clear();
+      for (int k = lo; k < hi; ++k) tmp.emplace_back(S.csr_col[k], S.csr_val[k]);
+      std::sort(tmp.begin(), tmp.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+      for (int k = lo; k < hi; ++k) { S.csr_col[k] = tmp[k - lo].first; S.csr_val[k] = tmp[k - lo].second; }
     }
   }
   for (int g = 0; g < S.ng; ++g) S.csc_ptr[g + 1] += S.csc_ptr[g];

@@ -40,7 +40,7 @@ class Options(C.Structure):
         ("max_time", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
         ("adapt_every", C.c_int32), ("check_every", C.c_int32), ("normalize", C.c_int32),
         ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("polish", C.c_int32), ("cert_tol", C.c_double), ("verbose", C.c_int32), ("device", C.c_int32),
-        ("interval_guard", C.c_double),
+        ("interval_guard", C.c_double), ("minv_mode", C.c_int32),
     ]
 
 
@@ -70,6 +70,7 @@ SYMBOLS = [
     ("nnsdp_solver_iterate_async", C.c_int, [C.c_void_p, C.c_int32]),
     ("nnsdp_solver_sync", C.c_int, [C.c_void_p]),
     ("nnsdp_solver_residuals", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("nnsdp_solver_apply_minv", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p, C.POINTER(C.c_int64)]),
     ("nnsdp_solver_run", C.c_int, [C.c_void_p, C.POINTER(Result)]),
     ("nnsdp_solver_finish", C.c_int, [C.c_void_p, C.POINTER(Result)]),
     ("nnsdp_solver_destroy", C.c_int, [C.c_void_p]),

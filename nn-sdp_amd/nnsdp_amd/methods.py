@@ -221,6 +221,7 @@ class AdmmSdpOptions:
     verbose: bool = False
     device: int = -1
     interval_guard: float = 5e-5   # relative floor on neuron interval half-widths inside the solver (see include/nnsdp.h)
+    minv_mode: int = 0             # 0 auto, 1 dense M^-1, 2 structured M^-1 (block-banded by layer + low rank; see include/nnsdp.h)
 
     def to_c(self) -> _lib.Options:
         o = _lib.Options()
@@ -241,6 +242,7 @@ class AdmmSdpOptions:
         o.verbose = int(bool(self.verbose))
         o.device = int(self.device)
         o.interval_guard = float(self.interval_guard)
+        o.minv_mode = int(self.minv_mode)
         return o
 
 
@@ -420,6 +422,17 @@ class Solver:
 
     def sync(self) -> None:
         _lib.check(self.lib.nnsdp_solver_sync(self.h))
+
+    def apply_minv(self, q):
+        """(M^-1 q, structured?, operand bytes): the Woodbury core applied to a full-length multiplier vector (test entry)."""
+        q = _f64(q)
+        if len(q) != self.cp.ngamma:
+            raise ValueError("q must have one entry per multiplier")
+        out = np.zeros_like(q)
+        st, nb = C.c_int32(), C.c_int64()
+        _lib.check(self.lib.nnsdp_solver_apply_minv(self.h, q.ctypes.data_as(_lib.c_double_p), out.ctypes.data_as(_lib.c_double_p),
+                                                    C.byref(st), C.byref(nb)))
+        return out, bool(st.value), int(nb.value)
 
     def residuals(self):
         a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()

@@ -532,7 +532,9 @@ def test_blocks_above_128_width_50_safety_query_in_the_reference_cliques():
                                   na.QcActivSector(acxdim=300, beta=0, smin=qo.qc_sector.smin, smax=qo.qc_sector.smax)])
     for mode, oname in ((na.SingleDecomp(), "single"), (na.DoubleDecomp(), "double")):
         iters = 150
-        s = na.runQuery(q, na.AdmmSdpOptions(max_iters=iters, decomp_mode=mode, polish=False))
+        # proj_tol: exact projections for the blocks of the Jacobi kernel too (the default is adaptive, i.e. loose early on,
+        # and this transient is sensitive: the objective is a sum of ~1200 multipliers of size 1e2 .. 1e3)
+        s = na.runQuery(q, na.AdmmSdpOptions(max_iters=iters, decomp_mode=mode, proj_tol=1e-12, polish=False))
         r = oadmm.admm_solve(oop.build_operator(qo, oname, normalize=True), oadmm.AdmmOptions(max_iters=iters))
         assert s.summary["iters"] == r.iters
         assert abs(s.objective_value - r.objective) <= 1e-5 * abs(r.objective) + 1e-9, (oname, s.objective_value, r.objective)
@@ -562,3 +564,36 @@ def test_baseline_configs_match_the_oracle_optimum(key):
         assert abs(s.objective_value - g["rho"]) <= tol, (key, type(mode).__name__, s.objective_value, g["rho"])
         assert abs(s.summary["objective_admm"] - g["rho"]) <= 0.1 * tol          # the raw iterates agree much more closely
         assert s.summary["lambda_max"] <= 1e-6 and min(np.min(s.values[k]) for k in ("γin", "γout", "γac1", "γac2")) >= 0.0
+
+
+def test_structured_minv_matches_the_dense_inverse():
+    """the Woodbury core M^-1 (M = I + A'D^-1A over the kept multipliers) in its structured form - block-banded by network layer
+    plus the low-rank term of the affine-affine entry, two-level domain decomposition, three launches (csrc/minv.hpp) - against
+    the dense inverse: same vector to 1e-10, a fraction of the bytes, and the same ADMM iterates."""
+    rng = np.random.default_rng(11)
+    for name, beta in (("W40-D20", 2), ("W40-D40", 0)):
+        q = helpers.product_query(helpers.load_problem(name, beta))
+        sd = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), minv_mode=1))
+        ss = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), minv_mode=2))
+        for _ in range(3):
+            v = rng.standard_normal(sd.cp.ngamma)
+            a, stra, ba = sd.apply_minv(v)
+            b, strb, bb = ss.apply_minv(v)
+            assert not stra and strb
+            assert np.abs(a - b).max() <= 1e-10 * np.abs(a).max(), (name, np.abs(a - b).max(), np.abs(a).max())
+        assert bb <= 0.5 * ba, (name, bb, ba)
+        sd.advance(1500); ss.advance(1500)
+        rd, rs = sd.finish(), ss.finish()
+        assert abs(rd.summary["objective_admm"] - rs.summary["objective_admm"]) <= 1e-7 * abs(rd.summary["objective_admm"])
+        sd.close(); ss.close()
+    # auto mode on a big multiplier count: W20-D100 beta = 7 (22 013 multipliers; dense inverse ~1 GB)
+    d = np.load(__import__("os").path.join(helpers.GOLDEN, "nets", "scale-I2-O2-W20-D100.npz"))
+    xd = [int(v) for v in d["xdims"]]
+    net = na.FeedFwdNet(xdims=xd, Ms=[np.array(d[f"M{k}"]) for k in range(len(xd) - 1)])
+    qq, _, _ = na.ellipsoidQuery(net, [0.5, 0.5], [1.5, 1.5], 7)
+    sa = na.Solver(qq, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp()))
+    out, structured, nbytes = sa.apply_minv(rng.standard_normal(sa.cp.ngamma))
+    assert structured and nbytes <= 200e6 and np.all(np.isfinite(out))
+    sa.close()
+    with pytest.raises(na._lib.NnsdpError):          # a 5-layer net has too few layers to cut: structured mode is refused, not faked
+        na.Solver(helpers.product_query(helpers.load_problem("W10-D5", 0)), na.AdmmSdpOptions(minv_mode=2))
