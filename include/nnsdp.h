@@ -208,8 +208,9 @@ int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const
 
 /* Batched projection onto the PSD cone, the hot kernel (replaces the cone handling inside MOSEK;
  * reference of the arithmetic: LinearAlgebra.eigen on Symmetric).  mats: `batch` symmetric
- * matrices back to back, matrix b is n[b] x n[b] column-major, n[b] <= 128.  out receives the
- * projections, eigvals (may be NULL) sum(n) eigenvalues.  in/out are HOST pointers. */
+ * matrices back to back, matrix b is n[b] x n[b] column-major.  Matrices up to 128 go through the LDS-resident Jacobi kernel
+ * (one launch for all of them), larger ones (up to 4096) one at a time through rocSOLVER dsyevd + rocBLAS dgemm.  out receives
+ * the projections, eigvals (may be NULL) sum(n) eigenvalues.  in/out are HOST pointers. */
 int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mats, double* out,
                               double* eigvals, double* kernel_ms);
 

@@ -206,6 +206,17 @@ __global__ void k_big_rescale(long long n2, const double* __restrict__ w, double
   if (i < n2 && kap != 1.0) { double wv = w[i]; nu[i] = wv + kap * (nu[i] - wv); }
 }
 
+// w_k = proj_PSD(sym(nu_k)) for one block of any size through rocSOLVER dsyevd + rocBLAS dgemm, all on the handle's stream
+static void project_big_block(rocblas_handle h, hipStream_t st, int n, const double* nuk, double* wk, double* A, double* T, double* Dv,
+                              double* Ev, rocblas_int* info, double* eig_out = nullptr) {
+  hipLaunchKernelGGL(k_big_sym, dim3((n + 255) / 256, n), dim3(256), 0, st, n, nuk, A);
+  RBCHK(rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, n, A, n, Dv, Ev, info));
+  hipLaunchKernelGGL(k_big_scale, dim3((n + 255) / 256, n), dim3(256), 0, st, n, A, Dv, T);
+  const double one = 1.0, zero = 0.0;
+  RBCHK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, T, n, A, n, &zero, wk, n));
+  if (eig_out) HIPCHK(hipMemcpyAsync(eig_out, Dv, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+}
+
 __global__ void k_symmetrize_lower(int n, int ld, double* A) {
   int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
   if (i < n && i > j) A[(size_t)i * ld + j] = A[(size_t)j * ld + i];  // copy lower (col j,row i) to upper
@@ -434,6 +445,7 @@ struct nnsdp_solver {
     if (opt.minv_mode < 0 || opt.minv_mode > 2) throw std::invalid_argument("minv_mode must be 0 (auto), 1 (dense) or 2 (structured)");
     if (opt.minv_mode == 2 || (opt.minv_mode == 0 && ng >= kStructuredMinvFrom)) {
       mplan = plan_minv(S);
+      if (mplan.ok && mplan.nS > 7000) mplan.ok = false;      // the separator residual is staged in LDS (8 nS bytes <= 64 KB)
       if (mplan.ok) minv_structured = true;
       else if (opt.minv_mode == 2) throw std::invalid_argument("structured M^-1 not applicable: too few layers or the generator table is not block-banded by layer");
     }
@@ -568,7 +580,7 @@ struct nnsdp_solver {
   void apply_structured_minv(const double* q, double* out, hipStream_t s_) {
     const int ng = S.ng;
     hipLaunchKernelGGL(k_minv_stage1, dim3(cdiv((long long)(ng + mdev.nslots) * 64, kThreads)), dim3(kThreads), 0, s_, mdev, q);
-    hipLaunchKernelGGL(k_minv_stage2, dim3(cdiv((long long)mdev.nS * 64, kThreads) + 1), dim3(kThreads), 0, s_, mdev, q);
+    hipLaunchKernelGGL(k_minv_stage2, dim3(cdiv(mdev.nS, (kThreads / 64) * kMinvRows) + 1), dim3(kThreads), (size_t)mdev.nS * sizeof(double), s_, mdev, q);
     hipLaunchKernelGGL(k_minv_stage3, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, s_, mdev, out);
   }
 
@@ -629,11 +641,7 @@ struct nnsdp_solver {
       const int n = cn[k];
       double* nuk = nu.p + S.ng + coff[k];
       double* wk = w.p + S.ng + coff[k];
-      hipLaunchKernelGGL(k_big_sym, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, nuk, big_A.p);
-      RBCHK(rocsolver_dsyevd(roc->h, rocblas_evect_original, rocblas_fill_lower, n, big_A.p, n, big_D.p, big_E.p, big_info.p));
-      hipLaunchKernelGGL(k_big_scale, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, big_A.p, big_D.p, big_T.p);
-      const double one = 1.0, zero = 0.0;
-      RBCHK(rocblas_dgemm(roc->h, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, big_T.p, n, big_A.p, n, &zero, wk, n));
+      project_big_block(roc->h, st, n, nuk, wk, big_A.p, big_T.p, big_D.p, big_E.p, big_info.p);
       hipLaunchKernelGGL(k_big_rescale, dim3(cdiv((long long)n * n, 256)), dim3(256), 0, st, (long long)n * n, wk, nuk, d_kappa());
     }
     HIPCHK(hipGetLastError());
@@ -1544,16 +1552,17 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   long long tot = 0, etot = 0;
   int nmax = 0;
   for (int b = 0; b < batch; ++b) {
-    if (cn[b] < 1 || cn[b] > 128) throw std::invalid_argument("matrix dimension must be in 1..128");
+    if (cn[b] < 1 || cn[b] > 4096) throw std::invalid_argument("matrix dimension must be in 1..4096");
     coff[b] = tot; eoff[b] = etot;
     tot += (long long)cn[b] * cn[b]; etot += cn[b];
-    nmax = std::max(nmax, cn[b]);
+    if (cn[b] <= 128) nmax = std::max(nmax, cn[b]);
   }
   coff[batch] = tot; eoff[batch] = etot;
   DBuf<int> dcn; DBuf<long long> dco, deo; DBuf<double> dnu, dw, dV, dE;
   dcn.upload(cn); dco.upload(coff); deo.upload(eoff);
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dE.alloc(etot);
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
+  nmax = std::max(nmax, 1);
   const int alg = proj_algorithm(nmax);
   bool v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
@@ -1564,7 +1573,28 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
-  launch_proj(a, batch, nmax, v_lds, lds, nullptr, alg);
+  {
+    // matrices up to 128 through the LDS-resident Jacobi kernel (one launch), larger ones through the library path
+    std::vector<int> cs, big;
+    std::vector<long long> os, es;
+    for (int b = 0; b < batch; ++b) {
+      if (cn[b] <= 128) { cs.push_back(cn[b]); os.push_back(coff[b]); es.push_back(eoff[b]); }
+      else big.push_back(b);
+    }
+    DBuf<int> dcs; DBuf<long long> dos, des;
+    if (!big.empty() && !cs.empty()) { dcs.upload(cs); dos.upload(os); des.upload(es); a.cn = dcs.p; a.coff = dos.p; a.eoff = des.p; }
+    if (!cs.empty()) launch_proj(a, (int)cs.size(), nmax, v_lds, lds, nullptr, alg);
+    if (!big.empty()) {
+      RocHandle rh;
+      RBCHK(rocblas_set_stream(rh.h, nullptr));
+      int nb = 0;
+      for (int b : big) nb = std::max(nb, cn[b]);
+      DBuf<double> A, T, Dv, Ev; DBuf<rocblas_int> info;
+      A.alloc((size_t)nb * nb); T.alloc((size_t)nb * nb); Dv.alloc(nb); Ev.alloc(nb); info.alloc(1);
+      for (int b : big) project_big_block(rh.h, nullptr, cn[b], dnu.p + coff[b], dw.p + coff[b], A.p, T.p, Dv.p, Ev.p, info.p, dE.p + eoff[b]);
+      HIPCHK(hipDeviceSynchronize());
+    }
+  }
   HIPCHK(hipEventRecord(e1, nullptr));
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());

@@ -186,9 +186,13 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage1(MinvDev m, const doubl
     const int lo = m.clo[j], n = m.chi[j] - lo;
     const double* col = m.Pinv + m.poff[j] + (size_t)(wid - lo) * n;    // symmetric: column = row
     const double* qq = q + lo;
-    double s = 0.0;
-    for (int i = lane; i < n; i += 64) s += col[i] * qq[i];
-    s = wave_sum(s);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = lane;
+    for (; i + 192 < n; i += 256) {          // four independent loads in flight per lane
+      s0 += col[i] * qq[i]; s1 += col[i + 64] * qq[i + 64]; s2 += col[i + 128] * qq[i + 128]; s3 += col[i + 192] * qq[i + 192];
+    }
+    for (; i < n; i += 64) s0 += col[i] * qq[i];
+    const double s = wave_sum((s0 + s1) + (s2 + s3));
     if (lane == 0) m.t[wid] = s;
     return;
   }
@@ -198,17 +202,25 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage1(MinvDev m, const doubl
   const int lo = m.clo[j], n = m.chi[j] - lo;
   const double* col = m.H + m.hoff[j] + (size_t)c * n;
   const double* qq = q + lo;
-  double s = 0.0;
-  for (int i = lane; i < n; i += 64) s += col[i] * qq[i];
-  s = wave_sum(s);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = lane;
+  for (; i + 192 < n; i += 256) {
+    s0 += col[i] * qq[i]; s1 += col[i + 64] * qq[i + 64]; s2 += col[i + 128] * qq[i + 128]; s3 += col[i + 192] * qq[i + 192];
+  }
+  for (; i < n; i += 64) s0 += col[i] * qq[i];
+  const double s = wave_sum((s0 + s1) + (s2 + s3));
   if (lane == 0) m.rpart[slot] = s;
 }
 
-// stage 2: xS = Sc^-1 (q_S - the two adjacent chunks' contributions), one wave per separator row; one extra block computes the
-// low-rank coefficients coef = kap (v'q) (one block, fixed order: deterministic)
+// stage 2: xS = Sc^-1 r, r = q_S - the two adjacent chunks' contributions.  Each block stages r in LDS once (three gathers per
+// entry) and its four waves take kMinvRows rows each; one extra block computes the low-rank coefficients coef = kap (v'q)
+// (one block, fixed order: deterministic).  Dynamic LDS: nS doubles.
+static constexpr int kMinvRows = 4;      // rows of Sc^-1 per wave
 __global__ __launch_bounds__(kThreads) void k_minv_stage2(MinvDev m, const double* __restrict__ q) {
+  extern __shared__ double rsh[];
   __shared__ double red[8];
-  const int nrow_blocks = (int)(((long long)m.nS * 64 + kThreads - 1) / kThreads);
+  const int rows_per_block = (kThreads / 64) * kMinvRows;
+  const int nrow_blocks = (m.nS + rows_per_block - 1) / rows_per_block;
   if ((int)blockIdx.x >= nrow_blocks) {
     double d[8];
     for (int a = 0; a < m.r; ++a) {
@@ -220,13 +232,22 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage2(MinvDev m, const doubl
       for (int a = 0; a < m.r; ++a) { double s = 0.0; for (int b = 0; b < m.r; ++b) s += m.kap[a * m.r + b] * d[b]; m.coef[a] = s; }
     return;
   }
-  const int srow = (int)(((long long)blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-  if (srow >= m.nS) return;
-  const double* col = m.Scinv + (size_t)srow * m.nS;
-  double acc = 0.0;
-  for (int c = lane; c < m.nS; c += 64) acc += col[c] * (q[m.sep_gen[c]] - m.rpart[m.slotA[c]] - m.rpart[m.slotB[c]]);
-  acc = wave_sum(acc);
-  if (lane == 0) m.xS[srow] = acc;
+  for (int c = threadIdx.x; c < m.nS; c += kThreads) rsh[c] = q[m.sep_gen[c]] - m.rpart[m.slotA[c]] - m.rpart[m.slotB[c]];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * rows_per_block + wv * kMinvRows;
+#pragma unroll
+  for (int rr = 0; rr < kMinvRows; ++rr) {
+    const int srow = row0 + rr;
+    if (srow >= m.nS) break;
+    const double* col = m.Scinv + (size_t)srow * m.nS;
+    double a0 = 0.0, a1 = 0.0;
+    int c = lane;
+    for (; c + 64 < m.nS; c += 128) { a0 += col[c] * rsh[c]; a1 += col[c + 64] * rsh[c + 64]; }
+    for (; c < m.nS; c += 64) a0 += col[c] * rsh[c];
+    const double acc = wave_sum(a0 + a1);
+    if (lane == 0) m.xS[srow] = acc;
+  }
 }
 
 // stage 3: x_Ij = t - H_j x_S (row-major copy of H_j: one wave per row), x_S as is; minus the low-rank term

@@ -79,7 +79,7 @@ def test_invalid_arguments_return_negative_codes():
     assert lib.nnsdp_make_cliques(3, xd.ctypes.data_as(_lib.c_int32_p), 0, 9, C.byref(n), C.byref(t), None, None) < 0   # mode
     assert [len(c) for c in na.makeCliques([5] + [50] * 6 + [5], 0, na.PathDecomp)] == [56] + [101] * 5   # 2W+1, not 3W+1
     with pytest.raises(_lib.NnsdpError):
-        na.project_psd_batched([np.zeros((200, 200))])          # n > 128 (checked before any device use)
+        na.project_psd_batched([np.zeros((4097, 4097))])        # n > 4096 (checked before any device use)
     with pytest.raises(ValueError):
         na.project_psd_batched([np.zeros((3, 4))])
     # mirror-side validation, like the reference's @assert in the QC constructors
