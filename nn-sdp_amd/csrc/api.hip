@@ -304,7 +304,7 @@ struct nnsdp_solver {
   MinvDev mdev{};
   DBuf<int> m_clo, m_chi, m_w0, m_w1, m_hslot0, m_chunk_of, m_sep_of, m_sep_gen, m_slot_chunk, m_slotA, m_slotB;
   DBuf<long long> m_poff, m_hoff;
-  DBuf<double> m_P, m_H, m_HT, m_Sc, m_v, m_kap, m_t, m_rpart, m_xS, m_coef;
+  DBuf<double> m_P, m_H, m_HT, m_Sc, m_v, m_kap, m_t, m_rpart, m_rvec, m_xS, m_coef;
   DBuf<double> symv_part;   // batch handles: partial products of the tiled symmetric M^-1 q
   double sigma = 1.0, proj_tol = 1e-4;
   hipStream_t st = nullptr;
@@ -445,7 +445,6 @@ struct nnsdp_solver {
     if (opt.minv_mode < 0 || opt.minv_mode > 2) throw std::invalid_argument("minv_mode must be 0 (auto), 1 (dense) or 2 (structured)");
     if (opt.minv_mode == 2 || (opt.minv_mode == 0 && ng >= kStructuredMinvFrom)) {
       mplan = plan_minv(S);
-      if (mplan.ok && mplan.nS > 7000) mplan.ok = false;      // the separator residual is staged in LDS (8 nS bytes <= 64 KB)
       if (mplan.ok) minv_structured = true;
       else if (opt.minv_mode == 2) throw std::invalid_argument("structured M^-1 not applicable: too few layers or the generator table is not block-banded by layer");
     }
@@ -492,35 +491,36 @@ struct nnsdp_solver {
   void build_structured_minv() {
     const MinvPlan& Q = mplan;
     MinvBlocks B = assemble_minv_blocks(S, Q);
-    const int ng = S.ng, nc = Q.nchunk, nS = Q.nS;
+    const int ng = S.ng, nc = Q.nchunk, nS = Q.nS, ldS = Q.ldS;
     DBuf<double> Tjs;
     m_P.upload(B.Tjj); Tjs.upload(B.Tjs); m_Sc.upload(B.Tss);
     m_H.alloc((size_t)Q.htot); m_HT.alloc((size_t)Q.htot);
+    m_H.zero(); m_HT.zero();
     DBuf<rocblas_int> info;
     info.alloc(1);
     const double one = 1.0, zero = 0.0, mone = -1.0;
     for (int j = 0; j < nc; ++j) {
-      const int n = Q.chi[j] - Q.clo[j], wj = Q.w1[j] - Q.w0[j];
+      const int n = Q.chi[j] - Q.clo[j], wj = Q.w1[j] - Q.w0[j], ldn = (n + 1) & ~1, ldw = (wj + 1) & ~1;
       double* Pj = m_P.p + Q.poff[j];
-      RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, n, Pj, n, info.p));
+      RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, n, Pj, ldn, info.p));
       HIPCHK(hipStreamSynchronize(st));
       if (info.download()[0] != 0) throw HipError("structured M^-1: Cholesky of a chunk block failed");
-      RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, n, Pj, n, info.p));
-      hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, n, Pj);
+      RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, n, Pj, ldn, info.p));
+      hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(n, 256), n), dim3(256), 0, st, n, ldn, Pj);
       if (wj > 0) {
         double* Hj = m_H.p + Q.hoff[j];
         const double* Tj = Tjs.p + Q.hoff[j];
-        RBCHK(rocblas_dgemm(roc->h, rocblas_operation_none, rocblas_operation_none, n, wj, n, &one, Pj, n, Tj, n, &zero, Hj, n));
-        RBCHK(rocblas_dgemm(roc->h, rocblas_operation_transpose, rocblas_operation_none, wj, wj, n, &mone, Tj, n, Hj, n, &one,
-                            m_Sc.p + (size_t)Q.w0[j] * nS + Q.w0[j], nS));
-        hipLaunchKernelGGL(k_minv_transpose, dim3(cdiv((long long)n * wj, 256)), dim3(256), 0, st, n, wj, Hj, m_HT.p + Q.hoff[j]);
+        RBCHK(rocblas_dgemm(roc->h, rocblas_operation_none, rocblas_operation_none, n, wj, n, &one, Pj, ldn, Tj, ldn, &zero, Hj, ldn));
+        RBCHK(rocblas_dgemm(roc->h, rocblas_operation_transpose, rocblas_operation_none, wj, wj, n, &mone, Tj, ldn, Hj, ldn, &one,
+                            m_Sc.p + (size_t)Q.w0[j] * ldS + Q.w0[j], ldS));
+        hipLaunchKernelGGL(k_minv_transpose, dim3(cdiv((long long)n * wj, 256)), dim3(256), 0, st, n, wj, ldn, ldw, Hj, m_HT.p + Q.hoff[j]);
       }
     }
-    RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, nS, m_Sc.p, nS, info.p));
+    RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, nS, m_Sc.p, ldS, info.p));
     HIPCHK(hipStreamSynchronize(st));
     if (info.download()[0] != 0) throw HipError("structured M^-1: Cholesky of the separator Schur complement failed");
-    RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, nS, m_Sc.p, nS, info.p));
-    hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(nS, 256), nS), dim3(256), 0, st, nS, nS, m_Sc.p);
+    RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, nS, m_Sc.p, ldS, info.p));
+    hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(nS, 256), nS), dim3(256), 0, st, nS, ldS, m_Sc.p);
     // index maps
     std::vector<int> sep_gen(nS), hslot0(nc), slot_chunk, slotA(nS), slotB(nS);
     for (int g = 0; g < ng; ++g) if (Q.sep_of[g] >= 0) sep_gen[Q.sep_of[g]] = g;
@@ -531,15 +531,15 @@ struct nnsdp_solver {
     m_clo.upload(Q.clo); m_chi.upload(Q.chi); m_w0.upload(Q.w0); m_w1.upload(Q.w1); m_hslot0.upload(hslot0);
     m_poff.upload(Q.poff); m_hoff.upload(Q.hoff); m_chunk_of.upload(Q.chunk_of); m_sep_of.upload(Q.sep_of);
     m_sep_gen.upload(sep_gen); m_slot_chunk.upload(slot_chunk); m_slotA.upload(slotA); m_slotB.upload(slotB);
-    m_t.alloc(ng); m_rpart.alloc(std::max(nslots, 1)); m_xS.alloc(std::max(nS, 1)); m_coef.alloc(8);
+    m_t.alloc(ng); m_rpart.alloc(std::max(nslots, 1)); m_xS.alloc(std::max(ldS, 2)); m_rvec.alloc(std::max(ldS, 2)); m_coef.alloc(8);
     m_v.alloc((size_t)ng * std::max(Q.r, 1)); m_kap.alloc(64);
-    m_v.zero(); m_kap.zero(); m_coef.zero();
-    mdev.ng = ng; mdev.nchunk = nc; mdev.nS = nS; mdev.r = 0; mdev.nslots = nslots;
+    m_v.zero(); m_kap.zero(); m_coef.zero(); m_rvec.zero(); m_xS.zero();
+    mdev.ng = ng; mdev.nchunk = nc; mdev.nS = nS; mdev.ldS = ldS; mdev.r = 0; mdev.nslots = nslots;
     mdev.clo = m_clo.p; mdev.chi = m_chi.p; mdev.w0 = m_w0.p; mdev.w1 = m_w1.p; mdev.hslot0 = m_hslot0.p;
     mdev.poff = m_poff.p; mdev.hoff = m_hoff.p; mdev.chunk_of = m_chunk_of.p; mdev.sep_of = m_sep_of.p; mdev.sep_gen = m_sep_gen.p;
     mdev.slot_chunk = m_slot_chunk.p; mdev.slotA = m_slotA.p; mdev.slotB = m_slotB.p;
     mdev.Pinv = m_P.p; mdev.H = m_H.p; mdev.HT = m_HT.p; mdev.Scinv = m_Sc.p; mdev.v = m_v.p; mdev.kap = m_kap.p;
-    mdev.t = m_t.p; mdev.rpart = m_rpart.p; mdev.xS = m_xS.p; mdev.coef = m_coef.p;
+    mdev.t = m_t.p; mdev.rpart = m_rpart.p; mdev.rvec = m_rvec.p; mdev.xS = m_xS.p; mdev.coef = m_coef.p;
     // low-rank part: v = T^-1 U (the structured apply with r = 0), kap = (diag(1/d) + U'v)^-1 on the host (r x r, r <= 8)
     if (Q.r > 0) {
       DBuf<double> U, V;
@@ -548,18 +548,16 @@ struct nnsdp_solver {
       for (int a = 0; a < Q.r; ++a) apply_structured_minv(U.p + (size_t)a * ng, V.p + (size_t)a * ng, st);
       HIPCHK(hipStreamSynchronize(st));
       std::vector<double> vh = V.download();
-      std::vector<double> Km((size_t)Q.r * Q.r, 0.0);
-      for (int a = 0; a < Q.r; ++a)
-        for (int b = 0; b < Q.r; ++b) {
+      const int r = Q.r;
+      std::vector<double> Km((size_t)r * r, 0.0), Ki((size_t)r * r, 0.0);
+      for (int a = 0; a < r; ++a)
+        for (int b = 0; b < r; ++b) {
           double sdot = a == b ? 1.0 / B.dU[a] : 0.0;
           for (int g = 0; g < ng; ++g) sdot += B.U[(size_t)a * ng + g] * vh[(size_t)b * ng + g];
-          Km[(size_t)a * Q.r + b] = sdot;
+          Km[(size_t)a * r + b] = sdot;
         }
-      // Gauss-Jordan inverse of the small symmetric positive definite matrix
-      const int r = Q.r;
-      std::vector<double> Ki((size_t)r * r, 0.0);
       for (int a = 0; a < r; ++a) Ki[(size_t)a * r + a] = 1.0;
-      for (int cidx = 0; cidx < r; ++cidx) {
+      for (int cidx = 0; cidx < r; ++cidx) {       // Gauss-Jordan on the small symmetric positive definite matrix
         const double pv = Km[(size_t)cidx * r + cidx];
         if (!(pv > 0.0)) throw HipError("structured M^-1: low-rank capacitance matrix is not positive definite");
         for (int b = 0; b < r; ++b) { Km[(size_t)cidx * r + b] /= pv; Ki[(size_t)cidx * r + b] /= pv; }
@@ -576,11 +574,12 @@ struct nnsdp_solver {
     HIPCHK(hipStreamSynchronize(st));
   }
 
-  // out = M^-1 q through the structured form: three dependent launches
+  // out = M^-1 q through the structured form: four dependent launches (the second is tiny)
   void apply_structured_minv(const double* q, double* out, hipStream_t s_) {
     const int ng = S.ng;
     hipLaunchKernelGGL(k_minv_stage1, dim3(cdiv((long long)(ng + mdev.nslots) * 64, kThreads)), dim3(kThreads), 0, s_, mdev, q);
-    hipLaunchKernelGGL(k_minv_stage2, dim3(cdiv(mdev.nS, (kThreads / 64) * kMinvRows) + 1), dim3(kThreads), (size_t)mdev.nS * sizeof(double), s_, mdev, q);
+    hipLaunchKernelGGL(k_minv_resid, dim3(cdiv(mdev.nS, kThreads) + 1), dim3(kThreads), 0, s_, mdev, q);
+    hipLaunchKernelGGL(k_minv_schur, dim3(cdiv((long long)mdev.nS * 64, kThreads)), dim3(kThreads), 0, s_, mdev);
     hipLaunchKernelGGL(k_minv_stage3, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, s_, mdev, out);
   }
 

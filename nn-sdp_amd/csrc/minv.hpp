@@ -29,7 +29,7 @@ struct MinvPlan {
   std::vector<int> lstart;               // generator range of every layer (nlayers + 1)
   std::vector<int> grow;                 // global pattern rows (low-rank part)
   // partition: pieces in generator order; chunk j = [clo[j], chi[j]), separators between them
-  int nchunk = 0, nS = 0;
+  int nchunk = 0, nS = 0, ldS = 0;
   std::vector<int> clo, chi;             // chunk generator ranges
   std::vector<int> slo, shi;             // separator generator ranges (nchunk - 1 of them; separator j sits after chunk j)
   std::vector<int> soff;                 // offset of separator j inside the packed separator vector (nchunk entries, last = nS)
@@ -99,9 +99,11 @@ inline MinvPlan plan_minv(const ScaledOperator& S, int target_chunk = 1024) {
     P.w1[j] = j + 1 < P.nchunk ? P.soff[j + 1] : P.nS;
     if (j == 0) P.w0[j] = 0;
     const long long n = P.chi[j] - P.clo[j], w = P.w1[j] - P.w0[j];
-    P.poff[j] = P.ptot; P.ptot += n * n;
-    P.hoff[j] = P.htot; P.htot += n * w;
+    const long long ldn = (n + 1) & ~1LL, ldw = (w + 1) & ~1LL;     // even leading dimensions: 16-byte aligned columns / rows
+    P.poff[j] = P.ptot; P.ptot += ldn * n;
+    P.hoff[j] = P.htot; P.htot += std::max(ldn * w, ldw * n);       // one offset serves H_j (ldn x w) and its row-major copy (n x ldw)
   }
+  P.ldS = (P.nS + 1) & ~1;
   // chunks must not couple with each other, nor with a separator that is not adjacent
   std::vector<char> glob(S.NE, 0);
   for (int e : P.grow) glob[e] = 1;
@@ -128,7 +130,7 @@ inline MinvBlocks assemble_minv_blocks(const ScaledOperator& S, const MinvPlan& 
   MinvBlocks B;
   B.Tjj.assign((size_t)P.ptot, 0.0);
   B.Tjs.assign((size_t)P.htot, 0.0);
-  B.Tss.assign((size_t)P.nS * P.nS, 0.0);
+  B.Tss.assign((size_t)P.ldS * std::max(P.nS, 1), 0.0);
   B.U.assign((size_t)P.ng * std::max(P.r, 1), 0.0);
   B.dU.assign(std::max(P.r, 1), 0.0);
   std::vector<char> glob(S.NE, 0);
@@ -141,13 +143,13 @@ inline MinvBlocks assemble_minv_blocks(const ScaledOperator& S, const MinvPlan& 
   auto add = [&](int gx, int gy, double v) {     // T[gx, gy] += v (both triangles are filled by symmetric calls)
     const int cx = P.chunk_of[gx], cy = P.chunk_of[gy];
     if (cx >= 0 && cy >= 0) {
-      const long long n = P.chi[cx] - P.clo[cx];
-      B.Tjj[P.poff[cx] + (long long)(gy - P.clo[cx]) * n + (gx - P.clo[cx])] += v;
+      const long long ldn = (P.chi[cx] - P.clo[cx] + 1) & ~1LL;
+      B.Tjj[P.poff[cx] + (long long)(gy - P.clo[cx]) * ldn + (gx - P.clo[cx])] += v;
     } else if (cx >= 0) {          // row in chunk, column in separator
-      const long long n = P.chi[cx] - P.clo[cx];
-      B.Tjs[P.hoff[cx] + (long long)(P.sep_of[gy] - P.w0[cx]) * n + (gx - P.clo[cx])] += v;
+      const long long ldn = (P.chi[cx] - P.clo[cx] + 1) & ~1LL;
+      B.Tjs[P.hoff[cx] + (long long)(P.sep_of[gy] - P.w0[cx]) * ldn + (gx - P.clo[cx])] += v;
     } else if (cy < 0) {
-      B.Tss[(size_t)P.sep_of[gy] * P.nS + P.sep_of[gx]] += v;
+      B.Tss[(size_t)P.sep_of[gy] * P.ldS + P.sep_of[gx]] += v;
     }                              // (separator row, chunk column) is the transpose of the case above: not stored
   };
   for (int e = 0; e < S.NE; ++e) {
@@ -165,7 +167,7 @@ inline MinvBlocks assemble_minv_blocks(const ScaledOperator& S, const MinvPlan& 
 
 // ---------------------------------------------------------------------------------------------- device side
 struct MinvDev {
-  int ng, nchunk, nS, r, nslots;
+  int ng, nchunk, nS, ldS, r, nslots;
   const int *clo, *chi, *w0, *w1, *hslot0;   // per chunk
   const long long *poff, *hoff;              // per chunk
   const int* chunk_of;                       // per generator (-1: separator)
@@ -174,54 +176,66 @@ struct MinvDev {
   const int* slot_chunk;                     // per H column slot: its chunk (slot = hslot0[j] + c)
   const int *slotA, *slotB;                  // per separator column: its slots in the left / right chunk
   const double *Pinv, *H, *HT, *Scinv, *v, *kap;   // v: ng x r, kap: r x r
-  double *t, *rpart, *xS, *coef;             // work: t[ng], rpart[nslots], xS[nS], coef[8]
+  double *t, *rpart, *rvec, *xS, *coef;      // work: t[ng], rpart[nslots], rvec[ldS], xS[nS], coef[8]
 };
 
-// stage 1: t = P_j q_Ij (one wave per chunk row), rpart[slot] = H_j[:, c]' q_Ij (one wave per slot)
-__global__ __launch_bounds__(kThreads) void k_minv_stage1(MinvDev m, const double* __restrict__ q) {
-  const int wid = (int)(((long long)blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-  if (wid < m.ng) {
-    const int j = m.chunk_of[wid];
-    if (j < 0) return;
-    const int lo = m.clo[j], n = m.chi[j] - lo;
-    const double* col = m.Pinv + m.poff[j] + (size_t)(wid - lo) * n;    // symmetric: column = row
-    const double* qq = q + lo;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = lane;
-    for (; i + 192 < n; i += 256) {          // four independent loads in flight per lane
-      s0 += col[i] * qq[i]; s1 += col[i + 64] * qq[i + 64]; s2 += col[i + 128] * qq[i + 128]; s3 += col[i + 192] * qq[i + 192];
-    }
-    for (; i < n; i += 64) s0 += col[i] * qq[i];
-    const double s = wave_sum((s0 + s1) + (s2 + s3));
-    if (lane == 0) m.t[wid] = s;
-    return;
-  }
-  const int slot = wid - m.ng;
-  if (slot >= m.nslots) return;
-  const int j = m.slot_chunk[slot], c = slot - m.hslot0[j];
-  const int lo = m.clo[j], n = m.chi[j] - lo;
-  const double* col = m.H + m.hoff[j] + (size_t)c * n;
-  const double* qq = q + lo;
+// dot product of two 16-byte aligned vectors of length n by one wave (the pattern of k_gemv_sym: 16-byte loads, two chains)
+__device__ __forceinline__ double wave_dot2(const double* __restrict__ a, const double* __restrict__ b, int n, int lane) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int i = lane;
-  for (; i + 192 < n; i += 256) {
-    s0 += col[i] * qq[i]; s1 += col[i + 64] * qq[i + 64]; s2 += col[i + 128] * qq[i + 128]; s3 += col[i + 192] * qq[i + 192];
+  int j = lane * 2;
+  for (; j + 129 < n; j += 256) {
+    const double2 a0 = *reinterpret_cast<const double2*>(a + j), b0 = *reinterpret_cast<const double2*>(b + j);
+    const double2 a1 = *reinterpret_cast<const double2*>(a + j + 128), b1 = *reinterpret_cast<const double2*>(b + j + 128);
+    s0 += a0.x * b0.x; s1 += a0.y * b0.y; s2 += a1.x * b1.x; s3 += a1.y * b1.y;
   }
-  for (; i < n; i += 64) s0 += col[i] * qq[i];
-  const double s = wave_sum((s0 + s1) + (s2 + s3));
-  if (lane == 0) m.rpart[slot] = s;
+  for (; j + 1 < n; j += 128) {
+    const double2 a0 = *reinterpret_cast<const double2*>(a + j), b0 = *reinterpret_cast<const double2*>(b + j);
+    s0 += a0.x * b0.x; s1 += a0.y * b0.y;
+  }
+  if (j < n) s0 += a[j] * b[j];
+  return wave_sum((s0 + s1) + (s2 + s3));
 }
 
-// stage 2: xS = Sc^-1 r, r = q_S - the two adjacent chunks' contributions.  Each block stages r in LDS once (three gathers per
-// entry) and its four waves take kMinvRows rows each; one extra block computes the low-rank coefficients coef = kap (v'q)
-// (one block, fixed order: deterministic).  Dynamic LDS: nS doubles.
-static constexpr int kMinvRows = 4;      // rows of Sc^-1 per wave
-__global__ __launch_bounds__(kThreads) void k_minv_stage2(MinvDev m, const double* __restrict__ q) {
-  extern __shared__ double rsh[];
+// stage 1: t = P_j q_Ij (one wave per chunk row), rpart[slot] = H_j[:, c]' q_Ij (one wave per slot).  q_Ij starts at an even
+// generator index only by luck, so the chunk's slice of q is read through an aligned copy-free path when clo[j] is even and
+// through scalar loads otherwise.
+__global__ __launch_bounds__(kThreads) void k_minv_stage1(MinvDev m, const double* __restrict__ q) {
+  const int wid = (int)(((long long)blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  int j, n, lo;
+  const double* col;
+  double* dst;
+  if (wid < m.ng) {
+    j = m.chunk_of[wid];
+    if (j < 0) return;
+    lo = m.clo[j]; n = m.chi[j] - lo;
+    col = m.Pinv + m.poff[j] + (size_t)(wid - lo) * ((n + 1) & ~1);      // symmetric: column = row
+    dst = m.t + wid;
+  } else {
+    const int slot = wid - m.ng;
+    if (slot >= m.nslots) return;
+    j = m.slot_chunk[slot];
+    lo = m.clo[j]; n = m.chi[j] - lo;
+    col = m.H + m.hoff[j] + (size_t)(slot - m.hslot0[j]) * ((n + 1) & ~1);
+    dst = m.rpart + slot;
+  }
+  const double* qq = q + lo;
+  double s;
+  if ((lo & 1) == 0) s = wave_dot2(col, qq, n, lane);
+  else {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = lane;
+    for (; i + 192 < n; i += 256) { s0 += col[i] * qq[i]; s1 += col[i + 64] * qq[i + 64]; s2 += col[i + 128] * qq[i + 128]; s3 += col[i + 192] * qq[i + 192]; }
+    for (; i < n; i += 64) s0 += col[i] * qq[i];
+    s = wave_sum((s0 + s1) + (s2 + s3));
+  }
+  if (lane == 0) *dst = s;
+}
+
+// stage 2a: r = q_S - the two adjacent chunks' contributions (one thread per separator entry); the LAST block computes the
+// low-rank coefficients coef = kap (v'q) (one block, fixed order: deterministic)
+__global__ __launch_bounds__(kThreads) void k_minv_resid(MinvDev m, const double* __restrict__ q) {
   __shared__ double red[8];
-  const int rows_per_block = (kThreads / 64) * kMinvRows;
-  const int nrow_blocks = (m.nS + rows_per_block - 1) / rows_per_block;
-  if ((int)blockIdx.x >= nrow_blocks) {
+  if (blockIdx.x == gridDim.x - 1) {
     double d[8];
     for (int a = 0; a < m.r; ++a) {
       double s = 0.0;
@@ -232,37 +246,32 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage2(MinvDev m, const doubl
       for (int a = 0; a < m.r; ++a) { double s = 0.0; for (int b = 0; b < m.r; ++b) s += m.kap[a * m.r + b] * d[b]; m.coef[a] = s; }
     return;
   }
-  for (int c = threadIdx.x; c < m.nS; c += kThreads) rsh[c] = q[m.sep_gen[c]] - m.rpart[m.slotA[c]] - m.rpart[m.slotB[c]];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * rows_per_block + wv * kMinvRows;
-#pragma unroll
-  for (int rr = 0; rr < kMinvRows; ++rr) {
-    const int srow = row0 + rr;
-    if (srow >= m.nS) break;
-    const double* col = m.Scinv + (size_t)srow * m.nS;
-    double a0 = 0.0, a1 = 0.0;
-    int c = lane;
-    for (; c + 64 < m.nS; c += 128) { a0 += col[c] * rsh[c]; a1 += col[c + 64] * rsh[c + 64]; }
-    for (; c < m.nS; c += 64) a0 += col[c] * rsh[c];
-    const double acc = wave_sum(a0 + a1);
-    if (lane == 0) m.xS[srow] = acc;
-  }
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c < m.nS) m.rvec[c] = q[m.sep_gen[c]] - m.rpart[m.slotA[c]] - m.rpart[m.slotB[c]];
 }
 
-// stage 3: x_Ij = t - H_j x_S (row-major copy of H_j: one wave per row), x_S as is; minus the low-rank term
+// stage 2b: xS = Sc^-1 r (symmetric, even leading dimension: one wave per row)
+__global__ __launch_bounds__(kThreads) void k_minv_schur(MinvDev m) {
+  const int srow = (int)(((long long)blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (srow >= m.nS) return;
+  const double s = wave_dot2(m.Scinv + (size_t)srow * m.ldS, m.rvec, m.nS, lane);
+  if (lane == 0) m.xS[srow] = s;
+}
+
+// stage 3: x_Ij = t - H_j x_S (row-major copy of H_j, rows padded to an even length: one wave per row), x_S as is; minus the
+// low-rank term
 __global__ __launch_bounds__(kThreads) void k_minv_stage3(MinvDev m, double* __restrict__ out) {
   const int g = (int)(((long long)blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (g >= m.ng) return;
   const int j = m.chunk_of[g];
   double x;
   if (j >= 0) {
-    const int lo = m.clo[j], wj = m.w1[j] - m.w0[j];
-    const double* row = m.HT + m.hoff[j] + (size_t)(g - lo) * wj;
+    const int lo = m.clo[j], wj = m.w1[j] - m.w0[j], ldw = (wj + 1) & ~1;
+    const double* row = m.HT + m.hoff[j] + (size_t)(g - lo) * ldw;
     const double* xs = m.xS + m.w0[j];
-    double s = 0.0;
-    for (int c = lane; c < wj; c += 64) s += row[c] * xs[c];
-    s = wave_sum(s);
+    double s;
+    if ((m.w0[j] & 1) == 0) s = wave_dot2(row, xs, wj, lane);
+    else { double s0 = 0.0; for (int c = lane; c < wj; c += 64) s0 += row[c] * xs[c]; s = wave_sum(s0); }
     x = m.t[g] - s;
   } else {
     x = m.xS[m.sep_of[g]];
@@ -273,12 +282,12 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage3(MinvDev m, double* __r
   }
 }
 
-// row-major copy of a column-major n x w block
-__global__ void k_minv_transpose(int n, int w, const double* __restrict__ H, double* __restrict__ HT) {
+// row-major copy (rows padded to ldw) of a column-major n x w block with leading dimension ldn
+__global__ void k_minv_transpose(int n, int w, int ldn, int ldw, const double* __restrict__ H, double* __restrict__ HT) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)n * w) return;
   const int i = (int)(idx % n), c = (int)(idx / n);
-  HT[(size_t)i * w + c] = H[idx];
+  HT[(size_t)i * ldw + c] = H[(size_t)c * ldn + i];
 }
 
 }  // namespace nnsdp
