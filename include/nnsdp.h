@@ -155,7 +155,9 @@ int nnsdp_solver_advance(nnsdp_solver* s, int32_t iters);
  * concurrently on one GPU; nnsdp_solver_sync waits for one handle. */
 int nnsdp_solver_iterate_async(nnsdp_solver* s, int32_t iters);
 int nnsdp_solver_sync(nnsdp_solver* s);
-/* relative residuals and objectives of the current iterate */
+/* ADVANCES the handle by ONE check iteration (an ordinary ADMM iteration that also accumulates the residual sums) and returns
+ * that iteration's relative residuals and primal / dual objective estimates; it does not stop, adapt the penalty or polish.
+ * After calling it on members of a batch handle, call nnsdp_batch_resync (the batch advances its members in lockstep). */
 int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* pobj, double* dobj);
 /* test / diagnostic entry: out = M^-1 q for a full-length multiplier vector q (entries of dropped multipliers are ignored and
  * returned as 0), through whichever form the handle uses; *structured (may be NULL) tells which, *operand_bytes its size */
@@ -177,6 +179,9 @@ int nnsdp_batch_create(nnsdp_solver** solvers, int32_t count, nnsdp_batch** out)
 int nnsdp_batch_iterate(nnsdp_batch* b, int32_t iters);
 int nnsdp_batch_run(nnsdp_batch* b, int32_t* status);
 int nnsdp_batch_destroy(nnsdp_batch* b);
+/* re-establish lockstep after members of the batch were advanced individually (nnsdp_solver_residuals / _iterate / _advance):
+ * the next batched iteration is a cold one for every member and the launch tables are rebuilt */
+int nnsdp_batch_resync(nnsdp_batch* b);
 /* result of a solver that stopped with `status` (as returned by nnsdp_batch_run): certificate polish, gamma, Z */
 int nnsdp_solver_finish_status(nnsdp_solver* s, int32_t status, nnsdp_result* r);
 

@@ -500,9 +500,13 @@ class SolverBatch:
         hs = (C.c_void_p * len(self.solvers))(*[s.h for s in self.solvers])
         _lib.check(self.lib.nnsdp_batch_create(hs, len(self.solvers), C.byref(self.h)))
 
+    def _resync(self) -> None:
+        _lib.check(self.lib.nnsdp_batch_resync(self.h))
+
     def advance(self, iters: int) -> None:
         for s in self.solvers:
             s.advance(iters)
+        self._resync()
 
     def iterate(self, iters: int) -> None:
         """exactly `iters` plain iterations of every SDP, one launch per stage for the whole batch."""
@@ -517,6 +521,7 @@ class SolverBatch:
             done += n
         for s in self.solvers:
             s.sync()
+        self._resync()
 
     def run(self) -> List[QuerySolution]:
         """full solves (stopping rules of runQuery, each SDP on its own) -> one QuerySolution per query."""
@@ -530,7 +535,10 @@ class SolverBatch:
         return out
 
     def residuals(self):
-        return [s.residuals() for s in self.solvers]
+        """one check iteration of every member (each advances by one iteration), then lockstep is re-established"""
+        out = [s.residuals() for s in self.solvers]
+        self._resync()
+        return out
 
     def finish(self):
         return [s.finish() for s in self.solvers]
