@@ -299,8 +299,6 @@ struct nnsdp_solver {
   DBuf<unsigned int> d_gidx;
   DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc, gs;
   // structured M^-1 (minv.hpp): used instead of the dense inverse for large multiplier counts
-  // projection stops on the rows that matter for the positive / negative split (ProjArgs.split_only); NNSDP_PROJ_FULL=1: diagnostic
-  bool split_only = [] { const char* e = std::getenv("NNSDP_PROJ_FULL"); return !(e && std::atoi(e) != 0); }();
   bool minv_structured = false;
   MinvPlan mplan;
   MinvDev mdev{};
@@ -630,7 +628,6 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    a.split_only = split_only ? 1 : 0;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
@@ -1193,7 +1190,6 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
-      q.split_only = s->split_only ? 1 : 0;
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));

@@ -65,12 +65,6 @@ struct ProjArgs {
   int warm;               // 1: use Vg as the starting basis
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
-  // split_only != 0 (ping-pong variant; the ADMM loop sets it): a PSD projection needs the positive / negative invariant
-  // SPLIT, not the eigenvectors.  The sweeps stop as soon as the off-diagonal ROWS that matter are below tol: the rows of the
-  // smaller sign class (the eigenpairs the rank-k reconstruction uses) and the rows whose diagonal is within the current
-  // off(A) of zero (an eigenvalue of the larger class can only change sign if its diagonal entry is that small).  Couplings
-  // inside the larger class are left as they are - they move its eigenvectors, not the projection.
-  int split_only = 0;
 };
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
@@ -583,28 +577,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6)
       for (int j = (tid & 63) + 1; j < i; j += 64) { double v = B0[pidx(i, j, 1)]; off2 += v * v; }
     off2 = 2.0 * block_sum(off2, red);
-    const bool split = a.split_only != 0;
-    // rows that matter for the projection (see ProjArgs.split_only): flags in sel[] (free until the reconstruction)
-    auto flag_rows = [&](double dmine, double tau) {      // dmine: true diagonal entry of position tid + 1 (tid < np)
-      const bool mine = tid < np;
-      const double cp = block_sum((mine && dmine > 0.0) ? 1.0 : 0.0, red);
-      const double cn_ = block_sum((mine && dmine < 0.0) ? 1.0 : 0.0, red);
-      const bool small_pos = cp <= cn_;
-      if (mine) sel[tid] = ((small_pos ? dmine > 0.0 : dmine < 0.0) || fabs(dmine) <= tau) ? 1 : 0;
-      __syncthreads();
-    };
-    double crit2 = off2;
-    if (split && off2 > thresh2) {
-      flag_rows(tid < np ? B0[pidx(tid + 1, tid + 1, 1)] : 0.0, sqrt(off2));
-      double c2 = 0.0;
-      for (int i = (tid >> 6) + 2; i <= np; i += NT >> 6) {
-        const int ci = sel[i - 1];
-        for (int j = (tid & 63) + 1; j < i; j += 64) { if (ci | sel[j - 1]) { double v = B0[pidx(i, j, 1)]; c2 += v * v; } }
-      }
-      crit2 = 2.0 * block_sum(c2, red);
-    }
     for (;;) {
-      if (crit2 <= thresh2 || sweeps >= a.max_sweeps) break;
+      if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
       if (!updater) {   // rotations of round 0 (type 0) straight from the matrix, all scales 1
         st_dp = 1.0; st_dq = 1.0;
         if (lane < m) {
@@ -755,20 +729,13 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         round(std::integral_constant<int, 1>{}, t + 1);
       }
       // back to true values: A_ij = d_i d_j a_ij, V_ij = d_j v_ij; the same pass measures off(A)^2 for the next decision
-      if (split) {    // row flags from the true diagonal of this sweep's result, tau = off(A) measured before the sweep
-        double dm = 0.0;
-        if (tid < np) { const double sc = dsc[tid]; dm = B0[pidx(tid + 1, tid + 1, 1)] * sc * sc; }
-        flag_rows(dm, sqrt(off2));
-      }
       off2 = 0.0;
-      double c2 = 0.0;
       for (int i = (tid >> 6) + 1; i <= np; i += NT >> 6) {
         const double di = dsc[i - 1];
-        const int ci = split ? sel[i - 1] : 1;
         for (int j = (tid & 63) + 1; j <= i; j += 64) {
           const double v = B0[pidx(i, j, 1)] * (di * dsc[j - 1]);
           B0[pidx(i, j, 1)] = v;
-          if (j < i) { off2 += v * v; if (ci | (split ? sel[j - 1] : 1)) c2 += v * v; }
+          if (j < i) off2 += v * v;
         }
       }
       if (lane < m) {
@@ -777,7 +744,6 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         for (int j = 0; j < VRW; ++j) { vr[j][0] *= da; vr[j][1] *= db; }
       }
       off2 = 2.0 * block_sum(off2, red);     // (two barriers: the rescaled matrix is visible to everybody afterwards)
-      crit2 = split ? 2.0 * block_sum(c2, red) : off2;
       ++sweeps;
     }
     // ---- eigenvalues back to the unshifted diagonal of A, eigenvectors (position order) to V
