@@ -37,7 +37,7 @@ def test_ipm_and_admm_agree_on_w10_d5():
 @pytest.mark.parametrize("key", sorted(GOLD))
 def test_committed_ipm_optimum_is_a_bracket_below_the_published_values(key):
     g = GOLD[key]
-    assert g["gap"] <= 1e-7 and g["pinf"] <= 1e-6 and g["dinf"] <= 1e-7 and g["lambda_max"] <= 1e-7
+    assert g["status"] in ("OPTIMAL", "NEAR_OPTIMAL") and g["gap"] <= 1e-7 and g["pinf"] <= 1e-6 and g["dinf"] <= 1e-7 and g["lambda_max"] <= 1e-6
     assert g["lower"] <= g["rho"] * (1 + 1e-9)
     pub = helpers.published_rho(g["net"], g["beta"])
     assert g["published"] == sorted(pub)
