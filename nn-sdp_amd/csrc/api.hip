@@ -315,6 +315,8 @@ struct nnsdp_solver {
   std::unique_ptr<RocHandle> roc;
   long long iters_done = 0, next_adapt = 0, next_trace = 0, next_cert = 500, best_iter = 0;
   double best_res = 1e300;
+  double lr_ema = 0.0;      // smoothed log of the balancing ratio sqrt(pres / dres)
+  bool have_ema = false;
   int trace_polish = 0;
   int since_cold = 0;
   double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
@@ -847,12 +849,33 @@ struct nnsdp_solver {
       else if (!advance_only && iters_done - best_iter >= 50000) return NNSDP_STATUS_SLOW_PROGRESS;
     }
     // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
+    // The balancing ratio is smoothed over the checks (the dual residual fluctuates by 3x from check to check), and the
+    // geometric back-off only starts when the penalty was actually changed: a check that finds the residuals balanced must
+    // not postpone the next look by half the iterations done so far (measured on W40-D20 Double: sigma sat at 0.0027 from
+    // iteration 3 250 to 7 250 with pres = 3-4 x dres, because the one look at 4 900 happened to fall on a dres spike).
+    static const int sigma_rule = [] { const char* e = std::getenv("NNSDP_SIGMA_RULE"); return e ? std::atoi(e) : 1; }();   // 0: round-1 rule (diagnostic)
+    {
+      const double lr = 0.5 * std::log(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
+      lr_ema = have_ema ? 0.7 * lr_ema + 0.3 * lr : lr;
+      have_ema = true;
+    }
     if (opt.adapt_every > 0 && iters_done >= next_adapt) {
       static const double geom = [] { const char* e = std::getenv("NNSDP_SIGMA_GEOM"); return e ? std::atof(e) : 1.5; }();   // diagnostic
       static const double powr = [] { const char* e = std::getenv("NNSDP_SIGMA_POW"); return e ? std::atof(e) : 1.0; }();    // diagnostic
-      next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, (long long)(iters_done * geom));
-      double ratio = std::pow(std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300)), powr);
-      if (ratio > 1.5 || ratio < 0.67) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
+      if (sigma_rule == 0) {
+        next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, (long long)(iters_done * geom));
+        double ratio = std::pow(std::sqrt(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300)), powr);
+        if (ratio > 1.5 || ratio < 0.67) set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
+      } else {
+        const double ratio = std::exp(powr * lr_ema);
+        if (ratio > 1.5 || ratio < 0.67) {
+          set_sigma(sigma * std::min(std::max(ratio, 0.2), 5.0));
+          next_adapt = std::max<long long>(iters_done + 2LL * opt.adapt_every, (long long)(iters_done * geom));
+          have_ema = false;      // the residuals of the old penalty say nothing about the new one
+        } else {
+          next_adapt = iters_done + opt.adapt_every;
+        }
+      }
     }
     return -1;
   }
