@@ -849,11 +849,11 @@ struct nnsdp_solver {
       else if (!advance_only && iters_done - best_iter >= 50000) return NNSDP_STATUS_SLOW_PROGRESS;
     }
     // residual balancing on a geometric schedule (adapting at a fixed period makes sigma oscillate)
-    // The balancing ratio is smoothed over the checks (the dual residual fluctuates by 3x from check to check), and the
-    // geometric back-off only starts when the penalty was actually changed: a check that finds the residuals balanced must
-    // not postpone the next look by half the iterations done so far (measured on W40-D20 Double: sigma sat at 0.0027 from
-    // iteration 3 250 to 7 250 with pres = 3-4 x dres, because the one look at 4 900 happened to fall on a dres spike).
-    static const int sigma_rule = [] { const char* e = std::getenv("NNSDP_SIGMA_RULE"); return e ? std::atoi(e) : 1; }();   // 0: round-1 rule (diagnostic)
+    // NNSDP_SIGMA_RULE=1 (diagnostic): the balancing ratio smoothed over the checks, geometric back-off only after an actual
+    // change.  Fixes single traces (W40-D20 Double: sigma sat at 0.0027 from iteration 3 250 to 7 250 with pres = 3-4 x dres
+    // because the one look at 4 900 fell on a dres spike) and changes nothing over 15 problems (negative result 15),
+    // so the default stays round 1's rule.
+    static const int sigma_rule = [] { const char* e = std::getenv("NNSDP_SIGMA_RULE"); return e ? std::atoi(e) : 0; }();
     {
       const double lr = 0.5 * std::log(std::max(last_pres, 1e-300) / std::max(last_dres, 1e-300));
       lr_ema = have_ema ? 0.7 * lr_ema + 0.3 * lr : lr;
