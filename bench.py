@@ -217,6 +217,11 @@ def main():
         eig_avg_s = eig_ms * 1e-3 / args.steps
         flops = float(sm["eig_flops_per_iter"])
         byts = float(sm["eig_bytes_per_iter"])
+        if shard:
+            # the timed kernel is rank 0's launch over ITS blocks: algorithmic work of those only
+            bn, st = na.shardPlan(q, opts, world)
+            flops = float(sum(10 * n ** 3 for n in bn[st[0]:st[1]]))
+            byts = float(sum(16 * n ** 2 for n in bn[st[0]:st[1]]))
         ach_tf = flops / eig_avg_s / 1e12
         out = {
             "metric": "ADMM iters/sec + wall-clock to eps-cert, bench/rand W=40 D=20",
