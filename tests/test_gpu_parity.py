@@ -612,3 +612,21 @@ def test_structured_minv_matches_the_dense_inverse():
     sa.close()
     with pytest.raises(na._lib.NnsdpError):          # a 5-layer net has too few layers to cut: structured mode is refused, not faked
         na.Solver(helpers.product_query(helpers.load_problem("W10-D5", 0)), na.AdmmSdpOptions(minv_mode=2))
+
+
+def test_degenerate_input_box_is_certified():
+    """an input coordinate with x1min == x1max is eliminated by the normalisation like a fixed neuron; its cost-free multiplier
+    gin_i is raised in the returned certificate (it used to stay 0 and the result was never certifiable)."""
+    d = helpers.load_problem("W10-D5", 0)
+    xd = [int(v) for v in d["xdims"]]
+    net = na.FeedFwdNet(xdims=xd, Ms=helpers.problem_Ms(d))
+    lo, hi = np.array([0.5, 1.0]), np.array([1.5, 1.0])
+    normal = np.array([1.0, 0.0])
+    q = na.ReachQuery(ffnet=net, qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_reach=na.QcReachHplane(normal=normal),
+                      qc_activs=na.makeQcActivs(net, lo, hi, 0))
+    s = na.runQuery(q, na.AdmmSdpOptions(max_iters=200000, eps_rel=1e-6))
+    assert s.termination_status == "OPTIMAL"
+    assert s.summary["lambda_max"] <= 1e-6 and min(np.min(s.values[k]) for k in ("γin", "γout", "γac1", "γac2")) >= 0.0
+    X = np.stack([0.5 + np.random.default_rng(0).random(5000), np.ones(5000)])
+    assert np.max(normal @ na.evalFeedFwdNet(net, X)) <= s.objective_value + 1e-9          # a sound bound on the slice
+    assert s.values["γin"][1] > 0.0                                                          # the eliminated coordinate's multiplier
