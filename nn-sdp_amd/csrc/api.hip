@@ -304,7 +304,7 @@ struct nnsdp_solver {
   MinvDev mdev{};
   DBuf<int> m_clo, m_chi, m_w0, m_w1, m_hslot0, m_chunk_of, m_sep_of, m_sep_gen, m_slot_chunk, m_slotA, m_slotB;
   DBuf<long long> m_poff, m_hoff;
-  DBuf<double> m_P, m_H, m_HT, m_Sc, m_v, m_kap, m_t, m_rpart, m_rvec, m_xS, m_coef;
+  DBuf<double> m_P, m_H, m_HT, m_Sc, m_v, m_kap, m_t, m_rpart, m_rvec, m_xS, m_coef, m_dpart;
   DBuf<double> symv_part;   // batch handles: partial products of the tiled symmetric M^-1 q
   double sigma = 1.0, proj_tol = 1e-4;
   hipStream_t st = nullptr;
@@ -535,13 +535,14 @@ struct nnsdp_solver {
     m_sep_gen.upload(sep_gen); m_slot_chunk.upload(slot_chunk); m_slotA.upload(slotA); m_slotB.upload(slotB);
     m_t.alloc(ng); m_rpart.alloc(std::max(nslots, 1)); m_xS.alloc(std::max(ldS, 2)); m_rvec.alloc(std::max(ldS, 2)); m_coef.alloc(8);
     m_v.alloc((size_t)ng * std::max(Q.r, 1)); m_kap.alloc(64);
-    m_v.zero(); m_kap.zero(); m_coef.zero(); m_rvec.zero(); m_xS.zero();
+    m_dpart.alloc(8 * kMinvParts);
+    m_v.zero(); m_kap.zero(); m_coef.zero(); m_rvec.zero(); m_xS.zero(); m_dpart.zero();
     mdev.ng = ng; mdev.nchunk = nc; mdev.nS = nS; mdev.ldS = ldS; mdev.r = 0; mdev.nslots = nslots;
     mdev.clo = m_clo.p; mdev.chi = m_chi.p; mdev.w0 = m_w0.p; mdev.w1 = m_w1.p; mdev.hslot0 = m_hslot0.p;
     mdev.poff = m_poff.p; mdev.hoff = m_hoff.p; mdev.chunk_of = m_chunk_of.p; mdev.sep_of = m_sep_of.p; mdev.sep_gen = m_sep_gen.p;
     mdev.slot_chunk = m_slot_chunk.p; mdev.slotA = m_slotA.p; mdev.slotB = m_slotB.p;
     mdev.Pinv = m_P.p; mdev.H = m_H.p; mdev.HT = m_HT.p; mdev.Scinv = m_Sc.p; mdev.v = m_v.p; mdev.kap = m_kap.p;
-    mdev.t = m_t.p; mdev.rpart = m_rpart.p; mdev.rvec = m_rvec.p; mdev.xS = m_xS.p; mdev.coef = m_coef.p;
+    mdev.t = m_t.p; mdev.rpart = m_rpart.p; mdev.rvec = m_rvec.p; mdev.xS = m_xS.p; mdev.coef = m_coef.p; mdev.dpart = m_dpart.p;
     // low-rank part: v = T^-1 U (the structured apply with r = 0), kap = (diag(1/d) + U'v)^-1 on the host (r x r, r <= 8)
     if (Q.r > 0) {
       DBuf<double> U, V;
@@ -579,7 +580,7 @@ struct nnsdp_solver {
   // out = M^-1 q through the structured form: four dependent launches (the second is tiny)
   void apply_structured_minv(const double* q, double* out, hipStream_t s_) {
     const int ng = S.ng;
-    hipLaunchKernelGGL(k_minv_stage1, dim3(cdiv((long long)(ng + mdev.nslots) * 64, kThreads)), dim3(kThreads), 0, s_, mdev, q);
+    hipLaunchKernelGGL(k_minv_stage1, dim3(cdiv((long long)(ng + mdev.nslots + kMinvParts) * 64, kThreads)), dim3(kThreads), 0, s_, mdev, q);
     hipLaunchKernelGGL(k_minv_resid, dim3(cdiv(mdev.nS, kThreads) + 1), dim3(kThreads), 0, s_, mdev, q);
     hipLaunchKernelGGL(k_minv_schur, dim3(cdiv((long long)mdev.nS * 64, kThreads)), dim3(kThreads), 0, s_, mdev);
     hipLaunchKernelGGL(k_minv_stage3, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, s_, mdev, out);

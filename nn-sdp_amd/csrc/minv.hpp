@@ -56,7 +56,7 @@ inline MinvPlan plan_minv(const ScaledOperator& S, int target_chunk = 1024) {
     if (hi - lo < 2) continue;
     int mn = 1 << 30, mx = -1;
     for (int k = lo; k < hi; ++k) { const int l = S.layer[S.csr_col[k]]; mn = std::min(mn, l); mx = std::max(mx, l); }
-    if (mx - mn > 2) P.grow.push_back(e);
+    if (mx - mn > 6) P.grow.push_back(e);       // (groups: two per network layer, see ProblemCopy::generator_layers)
     else bw = std::max(bw, mx - mn);
   }
   P.r = (int)P.grow.size();
@@ -68,6 +68,8 @@ inline MinvPlan plan_minv(const ScaledOperator& S, int target_chunk = 1024) {
   while (l < P.nlayers) {
     int l1 = l, cnt = 0;
     while (l1 < P.nlayers && (cnt == 0 || cnt + (P.lstart[l1 + 1] - P.lstart[l1]) <= target_chunk)) { cnt += P.lstart[l1 + 1] - P.lstart[l1]; ++l1; }
+    // a chunk ends on a whole-layer group (even index), so that the separator behind it is {straddling, layer, straddling}
+    if (l1 < P.nlayers && (l1 & 1) == 0 && l1 - 1 > l) --l1;
     piece_lo.push_back(l); piece_hi.push_back(l1); piece_is_sep.push_back(0);
     l = l1;
     if (l < P.nlayers) {
@@ -177,7 +179,9 @@ struct MinvDev {
   const int *slotA, *slotB;                  // per separator column: its slots in the left / right chunk
   const double *Pinv, *H, *HT, *Scinv, *v, *kap;   // v: ng x r, kap: r x r
   double *t, *rpart, *rvec, *xS, *coef;      // work: t[ng], rpart[nslots], rvec[ldS], xS[nS], coef[8]
+  double* dpart;                             // [8][kMinvParts] partial sums of v_a'q (stage 1), added in slot order (stage 2a)
 };
+static constexpr int kMinvParts = 32;
 
 // dot product of two 16-byte aligned vectors of length n by one wave (the pattern of k_gemv_sym: 16-byte loads, two chains)
 __device__ __forceinline__ double wave_dot2(const double* __restrict__ a, const double* __restrict__ b, int n, int lane) {
@@ -212,7 +216,19 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage1(MinvDev m, const doubl
     dst = m.t + wid;
   } else {
     const int slot = wid - m.ng;
-    if (slot >= m.nslots) return;
+    if (slot >= m.nslots) {
+      // kMinvParts extra waves: partial sums of the low-rank dots v_a'q over a slice of the multipliers
+      const int part = slot - m.nslots;
+      if (part >= kMinvParts) return;
+      const int per = (m.ng + kMinvParts - 1) / kMinvParts, i0 = part * per, i1 = min(i0 + per, m.ng);
+      for (int a = 0; a < m.r; ++a) {
+        double s = 0.0;
+        for (int i = i0 + lane; i < i1; i += 64) s += m.v[(size_t)a * m.ng + i] * q[i];
+        s = wave_sum(s);
+        if (lane == 0) m.dpart[a * kMinvParts + part] = s;
+      }
+      return;
+    }
     j = m.slot_chunk[slot];
     lo = m.clo[j]; n = m.chi[j] - lo;
     col = m.H + m.hoff[j] + (size_t)(slot - m.hslot0[j]) * ((n + 1) & ~1);
@@ -231,19 +247,15 @@ __global__ __launch_bounds__(kThreads) void k_minv_stage1(MinvDev m, const doubl
   if (lane == 0) *dst = s;
 }
 
-// stage 2a: r = q_S - the two adjacent chunks' contributions (one thread per separator entry); the LAST block computes the
-// low-rank coefficients coef = kap (v'q) (one block, fixed order: deterministic)
+// stage 2a: r = q_S - the two adjacent chunks' contributions (one thread per separator entry); the LAST block adds the partial
+// low-rank dots of stage 1 in slot order and applies kap: coef = kap (v'q) (deterministic)
 __global__ __launch_bounds__(kThreads) void k_minv_resid(MinvDev m, const double* __restrict__ q) {
-  __shared__ double red[8];
   if (blockIdx.x == gridDim.x - 1) {
-    double d[8];
-    for (int a = 0; a < m.r; ++a) {
-      double s = 0.0;
-      for (int i = threadIdx.x; i < m.ng; i += kThreads) s += m.v[(size_t)a * m.ng + i] * q[i];
-      d[a] = block_sum(s, red);
-    }
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+      double d[8];
+      for (int a = 0; a < m.r; ++a) { double s = 0.0; for (int p = 0; p < kMinvParts; ++p) s += m.dpart[a * kMinvParts + p]; d[a] = s; }
       for (int a = 0; a < m.r; ++a) { double s = 0.0; for (int b = 0; b < m.r; ++b) s += m.kap[a * m.r + b] * d[b]; m.coef[a] = s; }
+    }
     return;
   }
   const int c = blockIdx.x * kThreads + threadIdx.x;

@@ -39,18 +39,21 @@ struct ProblemCopy {
   std::vector<int> offs;  // z-offset of block k (size K+1, offs[K] = a = Zdim-1)
   std::vector<int> neuron_layer;   // hidden layer (0-based) of every neuron t
 
-  // network layer (0-based hidden layer) every multiplier belongs to: generators of layer k touch only the blocks of x_k,
-  // x_{k+1} (and the affine index); a repeated-nonlinearity pair counts for its later neuron
+  // ordering group of every multiplier: 2k for the multipliers of hidden layer k (their generators touch the blocks of x_k,
+  // x_{k+1} and the affine index only), 2k - 1 for the few repeated-nonlinearity pairs that straddle the boundary between
+  // layers k-1 and k (they touch x_{k-1}, x_k, x_{k+1}): kept apart so that a separator of the structured M^-1 (minv.hpp) is
+  // one layer plus its two small straddling groups instead of two whole layers
   std::vector<int> generator_layers() const {
     std::vector<int> L(ng, 0);
     const int o1 = nin + nout, ol = o1 + n1, ov = ol + acdim, oe = ov + npairs, on = oe + acdim;
     for (int t = 0; t < acdim; ++t) {
-      L[o1 + t] = L[ol + t] = neuron_layer[t];
-      if (activ == NNSDP_ACTIV_RELU) L[oe + t] = L[on + t] = neuron_layer[t];
+      L[o1 + t] = L[ol + t] = 2 * neuron_layer[t];
+      if (activ == NNSDP_ACTIV_RELU) L[oe + t] = L[on + t] = 2 * neuron_layer[t];
     }
     int r = 0;
     for (int i = 0; i < acdim - 1; ++i)
-      for (int j = i + 1; j < acdim && j - i <= beta; ++j, ++r) L[ov + r] = neuron_layer[j];
+      for (int j = i + 1; j < acdim && j - i <= beta; ++j, ++r)
+        L[ov + r] = neuron_layer[i] == neuron_layer[j] ? 2 * neuron_layer[j] : 2 * neuron_layer[j] - 1;
     return L;
   }
 
