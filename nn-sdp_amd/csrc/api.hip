@@ -293,11 +293,6 @@ struct nnsdp_solver {
   int ldm = 0;
   // device state
   DBuf<int> d_cn, d_sptr, d_stats, d_long;
-  bool tracking = false;               // small-side tracking state (k_proj_track)
-  DBuf<int> trk_fb, trk_meta, trk_idx;
-  DBuf<double> trk_U, trk_eig;
-  DBuf<long long> d_noff;
-  size_t trk_lds = 0;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -436,22 +431,7 @@ struct nnsdp_solver {
     }
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
-    d_stats.alloc(24); d_stats.zero();
-    {
-      // small-side tracking between full decompositions (k_proj_track): ping-pong size class only
-      static const bool want = [] { const char* e = std::getenv("NNSDP_TRACK"); return e && std::atoi(e) != 0; }();
-      tracking = want && big_idx.empty() && proj_alg == nnsdp::kProjPingPong && v_lds && nnsdp::proj_pp_ok(nmax);
-      if (tracking) {
-        std::vector<long long> noff(ncl + 1, 0);
-        for (int k = 0; k < ncl; ++k) noff[k + 1] = noff[k] + cn[k];
-        d_noff.upload(noff);
-        trk_fb.alloc(ncl); trk_meta.alloc(4 * (size_t)ncl); trk_idx.alloc(nnsdp::kTrkR * (size_t)ncl);
-        trk_fb.zero(); trk_meta.zero(); trk_idx.zero();
-        trk_U.alloc(nnsdp::kTrkR * (size_t)noff[ncl]); trk_U.zero();
-        trk_eig.alloc((size_t)noff[ncl]); trk_eig.zero();
-        trk_lds = nnsdp::trk_lds_bytes(nmax);
-      }
-    }
+    d_stats.alloc(4); d_stats.zero();
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -652,11 +632,6 @@ struct nnsdp_solver {
     a.max_sweeps = 15;
     a.tol = kProjTol;
     if (big_idx.empty()) {
-      if (k1 > k0 && tracking) {
-        a.trk_fb = trk_fb.p + k0; a.trk_meta = trk_meta.p + 4 * (size_t)k0; a.trk_idx = trk_idx.p + nnsdp::kTrkR * (size_t)k0;
-        a.trk_U = trk_U.p; a.noff = d_noff.p + k0; a.eig = trk_eig.p; a.eoff = d_noff.p + k0;
-        hipLaunchKernelGGL(nnsdp::k_proj_track, dim3(k1 - k0), dim3(1024), trk_lds, st, a, warm ? 0 : 1);
-      }
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
     }
@@ -1126,15 +1101,6 @@ struct nnsdp_solver {
       r->objective_admm = objective_admm;
     r->polish_shift = polished ? polish_shift : -1.0;
     r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
-      if (tracking && (opt.verbose || std::getenv("NNSDP_TRACK_STATS")) && iters_done > 0)
-        std::fprintf(stderr, "[nnsdp] tracked projections: %.1f %% of block visits (no convergence %.2f %%, proof failed %.2f %%), %.2f rounds\n",
-                     100.0 * stv[4] / ((double)iters_done * ncl), 100.0 * stv[5] / ((double)iters_done * ncl),
-                     100.0 * stv[6] / ((double)iters_done * ncl), stv[4] ? (double)stv[7] / stv[4] : 0.0);
-      if (tracking && std::getenv("NNSDP_TRACK_STATS")) {
-        std::fprintf(stderr, "[nnsdp] small-side size at full decompositions (0..15+):");
-        for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %d", stv[8 + i]);
-        std::fprintf(stderr, "\n");
-      }
       if (opt.verbose && stv.size() >= 4 && stv[3] > 0) std::fprintf(stderr, "[nnsdp] nontrivial rotations: %.2f %% of pair visits\n", 100.0 * stv[2] / stv[3]);
     }
   }

@@ -65,17 +65,7 @@ struct ProjArgs {
   int warm;               // 1: use Vg as the starting basis
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
-  // small-side tracking (k_proj_track, below).  All null when it is off.
-  int* trk_fb = nullptr;          // per block: 1 = the full decomposition has to run in this iteration, 0 = the tracked projection stands
-  int* trk_meta = nullptr;        // per block {tracked vectors, small side negative?, iterations since the last full decomposition, usable?}
-  int* trk_idx = nullptr;         // per block kTrkR eigen-indices (columns of Vg) of the tracked vectors
-  double* trk_U = nullptr;        // per block n x kTrkR tracked vectors (column-major, block k at kTrkR * noff[k])
-  const long long* noff = nullptr;  // prefix sums of the block dimensions
 };
-static constexpr int kTrkR = 8;          // tracked vectors per block: the smaller sign class of the spectrum + guards
-static constexpr int kTrkGuards = 3;
-static constexpr int kTrkMaxRounds = 5;
-static constexpr int kTrkRefresh = 64;   // full decomposition at least this often (the stale basis is the preconditioner)
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
 __device__ __forceinline__ int sym_at(int i, int j, int lda) { return i >= j ? i * lda + j : j * lda + i; }
@@ -221,7 +211,6 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   constexpr bool PP = ALG == 3;
   static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 5 || RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
-  if (a.trk_fb && a.trk_fb[k] == 0) return;   // the tracked projection of this iteration stands (k_proj_track): nothing to do
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // Jacobi dimension (even)
   const int npg = (n + 15) & ~15;  // storage / MFMA dimension (multiple of 16; zero rows, identity in V)
@@ -1269,43 +1258,6 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     double* vg = a.Vg + a.coff[k];
     for (int j = tid >> 6; j < n; j += NT >> 6)
       for (int i = tid & 63; i < n; i += 64) vg[(size_t)j * n + i] = V[i + (j + pofs) * ldv];
-    if (a.trk_meta) {
-      // new tracked set: the eigen-indices of the smaller sign class (sel[]) + the kTrkGuards eigenvalues of the other class
-      // closest to zero; the tracked vectors are the corresponding columns of the fresh basis
-      __syncthreads();
-      int* tix = reinterpret_cast<int*>(red);            // 16 doubles of scratch: 8 indices + count
-      if (tid == 0) {
-        int rt = 0;
-        bool okk = nsel + kTrkGuards <= kTrkR;
-        if (okk) {
-          for (int t = 0; t < nsel; ++t) tix[rt++] = sel[t];
-          for (int gcount = 0; gcount < kTrkGuards && rt < n; ++gcount) {
-            int best = -1;
-            double bv = 0.0;
-            for (int l = pofs; l < n + pofs; ++l) {
-              bool taken = false;
-              for (int t = 0; t < rt; ++t) taken = taken || tix[t] == l;
-              if (taken) continue;
-              const double dv = fabs(A[l * lda + l]);
-              if (best < 0 || dv < bv) { best = l; bv = dv; }
-            }
-            if (best >= 0) tix[rt++] = best;
-          }
-        }
-        tix[8] = rt;
-        if (a.stats) atomicAdd(&a.stats[8 + (nsel < 15 ? nsel : 15)], 1);   // histogram of the small-side size at full decompositions
-        int* meta = a.trk_meta + 4 * k;
-        meta[0] = rt; meta[1] = use_pos ? 0 : 1; meta[2] = 0; meta[3] = (okk && rt > 0) ? 1 : 0;
-        for (int t = 0; t < kTrkR; ++t) a.trk_idx[kTrkR * k + t] = t < rt ? tix[t] - pofs : -1;
-      }
-      __syncthreads();
-      const int rt = tix[8];
-      double* Ug = a.trk_U + kTrkR * a.noff[k];
-      for (int idx = tid; idx < rt * n; idx += NT) {
-        const int c = idx / n, i = idx - c * n;
-        Ug[(size_t)c * n + i] = V[i + (size_t)tix[c] * ldv];
-      }
-    }
   }
 #ifdef NNSDP_STAMPS
   if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
@@ -1321,299 +1273,6 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi_b(const ProjArgs* __restrict
   const int sdp = __builtin_amdgcn_readfirstlane(m.x), blk = __builtin_amdgcn_readfirstlane(m.y);   // wave-uniform: keep the arguments in SGPRs
   const ProjArgs a = args[sdp];
   proj_body<V_LDS, NT, ALG, SPW, RPW>(a, blk);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3t: small-side tracking.  Between two full decompositions the projection of a block only needs the eigenpairs of the
-// SMALLER sign class of sym(nu_k) (0-3 negative eigenvalues per block at the W40-D20 north star): W = A - A_- (or A_+ itself
-// when the positive side is the small one).  One workgroup per block keeps B = +-sym(nu_k) in LDS (sign chosen so that the
-// small side is the negative one), corrects the <= kTrkR tracked vectors U (small side + kTrkGuards of the other side nearest
-// to zero) with Davidson rounds preconditioned by the STALE eigenbasis (Vg, eig: the last full decomposition of this block):
-//     R = B U - U G,  G = U'BU;   U <- orth( U - Vc ((Vc' R) ./ (dc - diag G)) ),   Vc = stale vectors outside the tracked set
-// until the residual of the small-side columns is <= tol |A|_F, takes the Ritz pairs of G (8 x 8 Jacobi in one wave) and
-// PROVES completeness: B - B_-(tracked) + tol |A| I must have a Cholesky factorisation (a negative direction the tracked space
-// misses makes a pivot non-positive).  Any failure (no convergence, lost rank, failed proof, stale state, cold start, refresh
-// due) sets trk_fb[k] = 1 and the full Jacobi kernel launched right behind it does the block - and refreshes the tracked state;
-// on success it sets trk_fb[k] = 0 and that kernel's workgroup for the block exits at once.
-// ---------------------------------------------------------------------------------------------
-inline size_t trk_lds_bytes(int nmax) {
-  const size_t ld = (size_t)nmax | 1;
-  return ((size_t)nmax * ld + 3 * kTrkR * ld + 2 * (size_t)nmax + 3 * 64 + 8 + 24) * sizeof(double) + (16 + (size_t)nmax + 1) * sizeof(int);
-}
-__device__ __forceinline__ double sum16(double s) {   // sum over aligned groups of 16 lanes, valid in the group's first lane
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
-  return s;
-}
-// G[a][b] = sum_i X[i + a ld] Y[i + b ld] for a, b < 8 (1024 threads: 16 partial sums per entry)
-__device__ __forceinline__ void trk_gram(const double* X, const double* Yp, int n, int ld, int rt, double* out, int tid) {
-  const int e = tid >> 4, part = tid & 15, aa = e >> 3, bb = e & 7;
-  double s = 0.0;
-  if (aa < rt && bb < rt)
-    for (int i = part; i < n; i += 16) s += X[i + aa * ld] * Yp[i + bb * ld];
-  s = sum16(s);
-  if (part == 0) out[e] = s;
-}
-__global__ __launch_bounds__(1024) void k_proj_track(ProjArgs a, int force_full) {
-  constexpr int NT = 1024, NW = 16;
-  extern __shared__ double lds[];
-  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int* meta = a.trk_meta + 4 * k;
-  const int rt = meta[0], age = meta[2];
-  const bool neg = meta[1] != 0;
-  if (force_full || !a.warm || meta[3] == 0 || age >= kTrkRefresh || rt <= 0 || rt > kTrkR) {
-    if (tid == 0) a.trk_fb[k] = 1;
-    return;
-  }
-  const int n = a.cn[k];
-  const int ld = n | 1;
-  double* B = lds;                    // n x ld, symmetric, row-major
-  double* Up = B + (size_t)n * ld;    // tracked vectors, column c at c * ld
-  double* Rp = Up + kTrkR * ld;       // B U, residuals, corrected vectors, Ritz vectors
-  double* Dp = Rp + kTrkR * ld;       // scaled coefficients of the correction in the stale basis
-  double* dl = Dp + kTrkR * ld;       // stale eigenvalues (of B)
-  double* colb = dl + n;              // current column of the Cholesky factor
-  double* G = colb + n;               // 8 x 8
-  double* Sm = G + 64;
-  double* Y = Sm + 64;
-  double* th = Y + 64;                // 8 Ritz values
-  double* red = th + 8;               // 24 doubles of reduction scratch
-  int* cidx = reinterpret_cast<int*>(red + 24);   // 8 tracked eigen-indices, [8] = flag
-  int* cmask = cidx + 16;             // 1: stale eigen-index outside the tracked set
-  const double sgn = neg ? 1.0 : -1.0;
-  const double* nuk = a.nu + a.coff[k];
-  const double* vg = a.Vg + a.coff[k];
-  double* Ug = a.trk_U + kTrkR * a.noff[k];
-
-  for (int idx = tid; idx < n * n; idx += NT) { const int j = idx / n, i = idx - j * n; B[i * ld + j] = nuk[idx]; }
-  for (int idx = tid; idx < rt * n; idx += NT) { const int c = idx / n, i = idx - c * n; Up[i + c * ld] = Ug[idx]; }
-  if (tid < n) { dl[tid] = sgn * a.eig[a.eoff[k] + tid]; cmask[tid] = 1; }
-  if (tid < kTrkR) cidx[tid] = a.trk_idx[kTrkR * k + tid];
-  __syncthreads();
-  if (tid < rt) { const int j = cidx[tid]; if (j >= 0 && j < n) cmask[j] = 0; }
-  double fro2 = 0.0;
-  for (int idx = tid; idx < n * n; idx += NT) {
-    const int i = idx / n, j = idx - i * n;
-    if (j < i) {
-      const double v = sgn * 0.5 * (B[i * ld + j] + B[j * ld + i]);
-      B[i * ld + j] = v; B[j * ld + i] = v;
-      fro2 += 2.0 * v * v;
-    } else if (j == i) {
-      const double v = sgn * B[i * ld + i];
-      B[i * ld + i] = v;
-      fro2 += v * v;
-    }
-  }
-  fro2 = block_sum(fro2, red);
-  const double tolv = a.tol_dev ? *a.tol_dev : a.tol;
-  const double nrm = sqrt(fro2);
-  const double tau = tolv * nrm, floorv = 1e-3 * nrm * rsqrt((double)n);
-  if (!(fro2 > 0.0) || !(fro2 < 1e300)) { if (tid == 0) a.trk_fb[k] = 1; return; }
-
-  bool conv = false;
-  int rounds = 0;
-  for (int rnd = 0;; ++rnd) {
-    // B U
-    for (int t = tid; t < n * rt; t += NT) {
-      const int c = t / n, i = t - c * n;
-      const double* br = B + i * ld;
-      const double* uc = Up + c * ld;
-      double s = 0.0;
-      for (int j = 0; j < n; ++j) s += br[j] * uc[j];
-      Rp[i + c * ld] = s;
-    }
-    __syncthreads();
-    trk_gram(Up, Rp, n, ld, rt, G, tid);
-    __syncthreads();
-    auto Gs = [&](int p, int q) { return 0.5 * (G[p * 8 + q] + G[q * 8 + p]); };
-    double r2 = 0.0;
-    for (int t = tid; t < n * rt; t += NT) {
-      const int c = t / n, i = t - c * n;
-      double s = Rp[i + c * ld];
-      for (int p = 0; p < rt; ++p) s -= Up[i + p * ld] * Gs(p, c);
-      Rp[i + c * ld] = s;
-      if (Gs(c, c) < tau + floorv) r2 += s * s;
-    }
-    r2 = block_sum(r2, red);
-    rounds = rnd;
-    if (r2 <= tolv * tolv * fro2) { conv = true; break; }
-    if (rnd == kTrkMaxRounds) break;
-    // coefficients of the residuals in the stale basis, scaled by the Davidson denominators; one wave per stale vector
-    for (int j = wv; j < n; j += NW) {
-      if (!cmask[j]) { if (lane < rt) Dp[j + lane * ld] = 0.0; continue; }
-      const double v0 = lane < n ? vg[(size_t)j * n + lane] : 0.0;
-      const double v1 = lane + 64 < n ? vg[(size_t)j * n + lane + 64] : 0.0;
-      double pc[kTrkR];
-#pragma unroll
-      for (int c = 0; c < kTrkR; ++c) {
-        double s = 0.0;
-        if (c < rt) {
-          if (lane < n) s = v0 * Rp[lane + c * ld];
-          if (lane + 64 < n) s += v1 * Rp[lane + 64 + c * ld];
-        }
-        pc[c] = wave_sum(s);
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < kTrkR; ++c)
-          if (c < rt) {
-            double den = dl[j] - Gs(c, c);
-            if (fabs(den) < floorv) den = den < 0.0 ? -floorv : floorv;
-            Dp[j + c * ld] = -pc[c] / den;
-          }
-      }
-    }
-    __syncthreads();
-    for (int t = tid; t < n * rt; t += NT) {
-      const int c = t / n, i = t - c * n;
-      const double* dc = Dp + c * ld;
-      double s = Up[i + c * ld];
-#pragma unroll 4
-      for (int j = 0; j < n; ++j) s += vg[(size_t)j * n + i] * dc[j];
-      Rp[i + c * ld] = s;
-    }
-    __syncthreads();
-    trk_gram(Rp, Rp, n, ld, rt, Sm, tid);
-    __syncthreads();
-    if (tid == 0) {   // Cholesky of the rt x rt Gram matrix (lower, in place)
-      int okc = 1;
-      for (int c = 0; c < rt && okc; ++c) {
-        double d = Sm[c * 8 + c];
-        for (int p = 0; p < c; ++p) d -= Sm[c * 8 + p] * Sm[c * 8 + p];
-        if (!(d > 1e-20)) { okc = 0; break; }
-        const double l = sqrt(d);
-        Sm[c * 8 + c] = l;
-        for (int r = c + 1; r < rt; ++r) {
-          double v = Sm[r * 8 + c];
-          for (int p = 0; p < c; ++p) v -= Sm[r * 8 + p] * Sm[c * 8 + p];
-          Sm[r * 8 + c] = v / l;
-        }
-      }
-      cidx[8] = okc;
-    }
-    __syncthreads();
-    if (!cidx[8]) break;
-    if (tid < n) {   // U <- Un L^-T, one row per thread
-      double u[kTrkR];
-#pragma unroll
-      for (int c = 0; c < kTrkR; ++c) {
-        if (c < rt) {
-          double s = Rp[tid + c * ld];
-#pragma unroll
-          for (int p = 0; p < c; ++p) s -= u[p] * Sm[c * 8 + p];
-          u[c] = s / Sm[c * 8 + c];
-          Up[tid + c * ld] = u[c];
-        } else u[c] = 0.0;
-      }
-    }
-    __syncthreads();
-  }
-  if (!conv) {
-    if (tid == 0) { a.trk_fb[k] = 1; if (a.stats) atomicAdd(&a.stats[5], 1); }
-    return;
-  }
-  // ---- Ritz pairs of G (padded to 8 x 8 with a positive diagonal): cyclic Jacobi in wave 0, element (r, c) in lane 8 r + c
-  if (wv == 0) {
-    const int r8 = lane >> 3, c8 = lane & 7;
-    const double g0 = (r8 < rt && c8 < rt) ? 0.5 * (G[r8 * 8 + c8] + G[c8 * 8 + r8]) : (r8 == c8 ? nrm : 0.0);
-    wave_lds_sync();
-    G[lane] = g0;
-    Y[lane] = r8 == c8 ? 1.0 : 0.0;
-    double* ics = Sm;
-    double gf = wave_sum(g0 * g0);
-    gf = lane_bcast(gf, 0);
-    wave_lds_sync();
-    for (int sweep = 0; sweep < 12; ++sweep) {
-      double o = r8 != c8 ? G[lane] * G[lane] : 0.0;
-      o = wave_sum(o);
-      o = lane_bcast(o, 0);
-      if (o <= 1e-28 * gf) break;
-      for (int ir = 0; ir < 7; ++ir) {
-        if (lane < 4) {
-          const int p = pair_top(lane, ir, 7, 4), q = pair_bot(lane, ir, 7, 4);
-          double c, sn;
-          jacobi_cs(G[p * 8 + p], G[q * 8 + q], G[p * 8 + q], 0.0, c, sn);
-          ics[2 * lane] = c; ics[2 * lane + 1] = sn;
-        }
-        wave_lds_sync();
-        double n00 = 0, n01 = 0, n10 = 0, n11 = 0, y0 = 0, y1 = 0;
-        int p1 = 0, q1 = 0, p2 = 0, q2 = 0, yr = 0;
-        if (lane < 16) {
-          const int sa = lane >> 2, sb = lane & 3;
-          p1 = pair_top(sa, ir, 7, 4); q1 = pair_bot(sa, ir, 7, 4); p2 = pair_top(sb, ir, 7, 4); q2 = pair_bot(sb, ir, 7, 4);
-          const double c1 = ics[2 * sa], s1 = ics[2 * sa + 1], c2 = ics[2 * sb], s2 = ics[2 * sb + 1];
-          const double b00 = G[p1 * 8 + p2], b01 = G[p1 * 8 + q2], b10 = G[q1 * 8 + p2], b11 = G[q1 * 8 + q2];
-          const double t00 = c1 * b00 - s1 * b10, t01 = c1 * b01 - s1 * b11, t10 = s1 * b00 + c1 * b10, t11 = s1 * b01 + c1 * b11;
-          n00 = c2 * t00 - s2 * t01; n01 = s2 * t00 + c2 * t01; n10 = c2 * t10 - s2 * t11; n11 = s2 * t10 + c2 * t11;
-        } else if (lane >= 32) {
-          yr = (lane - 32) >> 2;
-          const int sb = lane & 3;
-          p2 = pair_top(sb, ir, 7, 4); q2 = pair_bot(sb, ir, 7, 4);
-          const double c2 = ics[2 * sb], s2 = ics[2 * sb + 1];
-          const double a0 = Y[yr * 8 + p2], a1 = Y[yr * 8 + q2];
-          y0 = c2 * a0 - s2 * a1; y1 = s2 * a0 + c2 * a1;
-        }
-        wave_lds_sync();
-        if (lane < 16) { G[p1 * 8 + p2] = n00; G[p1 * 8 + q2] = n01; G[q1 * 8 + p2] = n10; G[q1 * 8 + q2] = n11; }
-        else if (lane >= 32) { Y[yr * 8 + p2] = y0; Y[yr * 8 + q2] = y1; }
-        wave_lds_sync();
-      }
-    }
-    if (lane < 8) th[lane] = G[lane * 9];
-  }
-  __syncthreads();
-  // Ritz vectors Z = U Y
-  for (int t = tid; t < n * rt; t += NT) {
-    const int c = t / n, i = t - c * n;
-    double s = 0.0;
-    for (int p = 0; p < rt; ++p) s += Up[i + p * ld] * Y[p * 8 + c];
-    Rp[i + c * ld] = s;
-  }
-  __syncthreads();
-  // W, and M = B - B_-(tracked) + tau I (in place of B) for the completeness proof
-  double tn[kTrkR];
-#pragma unroll
-  for (int c = 0; c < kTrkR; ++c) tn[c] = (c < rt && th[c] < 0.0) ? th[c] : 0.0;
-  double* wk = a.w + a.coff[k];
-  for (int idx = tid; idx < n * n; idx += NT) {
-    const int j = idx / n, i = idx - j * n;
-    const double b = B[i * ld + j];
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < kTrkR; ++c) if (c < rt) s += tn[c] * Rp[i + c * ld] * Rp[j + c * ld];
-    wk[idx] = neg ? b - s : -s;
-    B[i * ld + j] = b - s + (i == j ? tau : 0.0);
-  }
-  __syncthreads();
-  bool pd = true;
-  for (int kk = 0; kk < n; ++kk) {
-    const double piv = B[kk * ld + kk];
-    if (!(piv > 0.0)) { pd = false; break; }
-    const double rs = rsqrt_nr(piv);
-    if (tid > kk && tid < n) colb[tid] = B[tid * ld + kk] * rs;
-    __syncthreads();
-    const int m = n - kk - 1;
-    for (int ii = tid >> 5; ii < m; ii += NT >> 5) {
-      const int i = kk + 1 + ii;
-      const double ci = colb[i];
-      for (int jj = tid & 31; jj <= ii; jj += 32) B[i * ld + kk + 1 + jj] -= ci * colb[kk + 1 + jj];
-    }
-    __syncthreads();
-  }
-  if (!pd) {
-    if (tid == 0) { a.trk_fb[k] = 1; if (a.stats) atomicAdd(&a.stats[6], 1); }
-    return;
-  }
-  if (tid == 0) {
-    a.trk_fb[k] = 0; meta[2] = age + 1;
-    if (a.stats) { atomicAdd(&a.stats[4], 1); atomicAdd(&a.stats[7], rounds); }
-  }
-  for (int idx = tid; idx < rt * n; idx += NT) { const int c = idx / n, i = idx - c * n; Ug[idx] = Rp[i + c * ld]; }
-  const double kap = a.kappa ? *a.kappa : 1.0;
-  if (kap != 1.0) {
-    double* nuw = a.nu + a.coff[k];
-    for (int idx = tid; idx < n * n; idx += NT) { const double wvv = wk[idx]; nuw[idx] = wvv + kap * (nuw[idx] - wvv); }
-  }
 }
 
 // launch: projection algorithm by the largest block of the launch.
@@ -1683,7 +1342,6 @@ inline hipError_t proj_allow_big_lds() {
   hipError_t e = hipSuccess;
 #define NNSDP_SET_LDS(K) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   NNSDP_PROJ_VARIANTS(NNSDP_SET_LDS)
-  NNSDP_SET_LDS(k_proj_track)
 #undef NNSDP_SET_LDS
   return e;
 }
