@@ -575,7 +575,9 @@ def test_baseline_configs_match_the_oracle_optimum(key):
     assert max(g["pres"], g["dres"]) <= 2e-6 and g["gamma_min"] >= 0.0
     for mode in (na.DoubleDecomp(), na.SingleDecomp()):
         s = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=mode, max_iters=400000, eps_rel=1e-6, max_time=150))
-        assert s.termination_status == "OPTIMAL", (key, type(mode).__name__, s.termination_status, s.summary)
+        # (W40-D40 Single creeps over the last 10 % of the way to 1e-6 and can trip the 50 000-iteration stall detector first)
+        assert s.termination_status in ("OPTIMAL", "SLOW_PROGRESS") and max(s.summary["pres"], s.summary["dres"]) <= 2e-6, \
+            (key, type(mode).__name__, s.termination_status, s.summary)
         tol = 1e-3 * abs(g["rho"]) + 1e-9
         assert abs(s.objective_value - g["rho"]) <= tol, (key, type(mode).__name__, s.objective_value, g["rho"])
         assert abs(s.summary["objective_admm"] - g["rho"]) <= 0.1 * tol          # the raw iterates agree much more closely
