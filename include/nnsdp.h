@@ -211,6 +211,14 @@ int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const
                          double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
                          double* ymin, double* ymax);
 
+/* Sampled forward pass on the GPU: Y[:, s] = ffnet(X[:, s]) for N points in fp64.  Replaces the
+ * N = 1e5 calls of evalFeedFwdNet (src/MyNeuralNetwork/MyNeuralNetwork.jl:40-48) inside Utils.sampleTrajs (src/Utils/qc.jl:40-47),
+ * whose outputs shape the ellipsoid of NnSdp.findEllipsoid (approxEllipsoid, src/Utils/qc.jl:50-67).  K, xdims, M as in
+ * nnsdp_problem; activ = NNSDP_ACTIV_*; X is xdims[0] x N, Y is xdims[K] x N, both column-major and caller-owned.
+ * kernel_ms (may be NULL) receives the HIP-event time of the launch.  Layer widths up to 639. */
+int nnsdp_eval_network(int32_t K, const int32_t* xdims, const double* M, int32_t activ, int64_t N, const double* X, double* Y,
+                       double* kernel_ms);
+
 /* Batched projection onto the PSD cone, the hot kernel (replaces the cone handling inside MOSEK;
  * reference of the arithmetic: LinearAlgebra.eigen on Symmetric).  mats: `batch` symmetric
  * matrices back to back, matrix b is n[b] x n[b] column-major.  Matrices up to 128 go through the LDS-resident Jacobi kernel

@@ -111,6 +111,24 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
                        termination_status = status, total_time = res.t_total, setup_time = res.t_setup, solve_time = res.t_solve)
 end
 
+# Utils.sampleTrajs (src/Utils/qc.jl:40-47) with the N forward passes on the GPU (nnsdp_eval_network, fp64): same return value,
+# a Vector of output vectors; Utils.approxEllipsoid (qc.jl:50-67) works on it unchanged.
+function sampleTrajsGpu(ffnet::FeedFwdNet, x1min::VecReal, x1max::VecReal, N=Int(1e5))
+  @assert length(x1min) == length(x1max) == ffnet.xdims[1]
+  xdims = Int32.(ffnet.xdims)
+  M = vcat([vec(Matrix{Float64}(Mk)) for Mk in ffnet.Ms]...)
+  X = x1min .+ rand(ffnet.xdims[1], N) .* (x1max - x1min)            # xdims[1] x N, column-major as the library expects
+  Y = zeros(ffnet.xdims[end], N)
+  activ = ffnet.activ isa TanhActiv ? Int32(1) : Int32(0)
+  GC.@preserve xdims M X Y begin
+    rc = ccall((:nnsdp_eval_network, LIBNNSDP), Cint,
+               (Int32, Ptr{Int32}, Ptr{Float64}, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+               Int32(ffnet.K), pointer(xdims), pointer(M), activ, Int64(N), pointer(X), pointer(Y), C_NULL)
+    rc == 0 || error("nnsdp_eval_network failed ($rc): " * unsafe_string(ccall((:nnsdp_last_error, LIBNNSDP), Cstring, ())))
+  end
+  return [Y[:, j] for j in 1:N]
+end
+
 # Interval pre-processing without the PyCall / ONNX / auto_LiRPA bridge (replaces Intervals.intervalsAutoLirpaSliced,
 # src/Intervals/intervals_auto_lirpa.jl:12-64, and the sector test of Qc.makeSectorMinMax, src/Qc/activ_sector.jl:63-72).
 # Drop-in for Qc.makeQcActivs (src/Qc/activ.jl:45-72): same return value.

@@ -18,6 +18,7 @@
 #include "setup.hpp"
 #include "minv.hpp"
 #include "intervals.hpp"
+#include "forward.hpp"
 
 namespace nnsdp {
 
@@ -1561,6 +1562,50 @@ int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const
     if (ymin) ymin[i] = iv.xlo[K][i];
     if (ymax) ymax[i] = iv.xhi[K][i];
   }
+  API_END
+}
+
+int nnsdp_eval_network(int32_t K, const int32_t* xdims, const double* M, int32_t activ, int64_t N, const double* X, double* Y,
+                       double* kernel_ms) {
+  API_BEGIN
+  if (K < 1 || !xdims || !M) throw std::invalid_argument("null / empty network");
+  if (N < 0) throw std::invalid_argument("N must be >= 0");
+  if (activ != NNSDP_ACTIV_RELU && activ != NNSDP_ACTIV_TANH) throw std::invalid_argument("unknown activation");
+  if (N == 0) return 0;
+  if (!X || !Y) throw std::invalid_argument("null argument");
+  require_gpu();
+  std::vector<int> xd(xdims, xdims + K + 1);
+  std::vector<long long> moff(K + 1, 0);
+  int wp = 0;
+  for (int k = 0; k < K; ++k) {
+    if (xd[k] < 1 || xd[k + 1] < 1) throw std::invalid_argument("layer widths must be >= 1");
+    moff[k + 1] = moff[k] + (long long)xd[k + 1] * (xd[k] + 1);
+    wp = std::max(wp, (xd[k] + 1 + 3) & ~3);
+  }
+  const size_t lds = 2 * (size_t)wp * 16 * sizeof(double);
+  if (lds > 160 * 1024) throw std::invalid_argument("layer width above 639 is not supported by the sampled forward pass");
+  if ((N + 15) / 16 > 0x7fffffffLL) throw std::invalid_argument("too many samples for one launch");
+  DBuf<int> dxd; DBuf<long long> dmo; DBuf<double> dM, dX, dY;
+  dxd.upload(xd); dmo.upload(moff);
+  dM.alloc(moff[K]); dX.alloc((size_t)xd[0] * N); dY.alloc((size_t)xd[K] * N);
+  HIPCHK(hipMemcpy(dM.p, M, moff[K] * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dX.p, X, (size_t)xd[0] * N * sizeof(double), hipMemcpyHostToDevice));
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nnsdp::k_forward_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  nnsdp::FwdArgs a;
+  a.K = K; a.xdims = dxd.p; a.moff = dmo.p; a.M = dM.p; a.X = dX.p; a.Y = dY.p; a.N = N; a.activ = activ; a.wp = wp;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(nnsdp::k_forward_mfma, dim3((unsigned)((N + 15) / 16)), dim3(64), lds, nullptr, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e1, nullptr));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  if (kernel_ms) *kernel_ms = ms;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  HIPCHK(hipMemcpy(Y, dY.p, (size_t)xd[K] * N * sizeof(double), hipMemcpyDeviceToHost));
   API_END
 }
 

@@ -7,7 +7,7 @@ from .methods import (  # noqa: F401
     runQuery, runQueries, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched, comm_unique_id, shardPlan,
 )
 from .frontend import (  # noqa: F401
-    read_nnet, evalFeedFwdNet, randomNetwork, makeIntervalsInfo, makeQcActivs, approxEllipsoid,
+    read_nnet, evalFeedFwdNet, evalFeedFwdNetBatch, sampleTrajs, randomNetwork, makeIntervalsInfo, makeQcActivs, approxEllipsoid,
     findEllipsoid, findCircle, findReach2Dpoly, write_scale_csv, runScale, ellipsoidQuery,
 )
 from . import _lib  # noqa: F401

@@ -16,6 +16,8 @@ from __future__ import annotations
 import csv
 from typing import List, Sequence, Tuple
 
+import ctypes as C
+
 import numpy as np
 
 from . import methods as M
@@ -184,11 +186,38 @@ def makeQcActivs(net: M.FeedFwdNet, x1min, x1max, beta: int):
 
 
 # ----------------------------------------------------------------------------- f2: callers of the path
-def approxEllipsoid(net: M.FeedFwdNet, x1min, x1max, N: int = 100000, seed: int = 1234):
+def evalFeedFwdNetBatch(net: M.FeedFwdNet, X, return_ms: bool = False):
+    """the network at the columns of X (xdims[0] x N) on the GPU: nnsdp_eval_network (csrc/forward.hpp, fp64 MFMA, one wave per
+    16 samples).  No host fallback: raises without a GPU.  evalFeedFwdNet above is the reference's pointwise function."""
+    lib = _lib.load()
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim != 2 or X.shape[0] != net.xdims[0]:
+        raise ValueError("X must be xdims[0] x N")
+    N = X.shape[1]
+    xd = np.asarray(net.xdims, dtype=np.int32)
+    Mp = np.concatenate([np.asfortranarray(Mk, dtype=np.float64).ravel(order="F") for Mk in net.Ms])
+    Xc = np.ascontiguousarray(X.T)                      # column-major xdims[0] x N
+    Y = np.empty((N, int(xd[-1])), dtype=np.float64)
+    ms = C.c_double(0.0)
+    dp = _lib.c_double_p
+    _lib.check(lib.nnsdp_eval_network(net.K, xd.ctypes.data_as(_lib.c_int32_p), Mp.ctypes.data_as(dp), M._activ_code(net.activ), N,
+                                      Xc.ctypes.data_as(dp), Y.ctypes.data_as(dp), C.byref(ms)))
+    return (Y.T, ms.value) if return_ms else Y.T
+
+
+def sampleTrajs(net: M.FeedFwdNet, x1min, x1max, N: int = 100000, seed: int = 1234):
+    """Utils.sampleTrajs (src/Utils/qc.jl:40-47): outputs of N inputs drawn uniformly from the box, xdims[K] x N.  The draw is
+    numpy's default_rng(seed) on the host (the Julia stream of the reference cannot be regenerated); the N forward passes run
+    on the GPU."""
     rng = np.random.default_rng(seed)
     x1min = np.asarray(x1min, dtype=np.float64)
     x1max = np.asarray(x1max, dtype=np.float64)
-    Y = evalFeedFwdNet(net, x1min[:, None] + rng.random((net.xdims[0], N)) * (x1max - x1min)[:, None])
+    return evalFeedFwdNetBatch(net, x1min[:, None] + rng.random((net.xdims[0], N)) * (x1max - x1min)[:, None])
+
+
+def approxEllipsoid(net: M.FeedFwdNet, x1min, x1max, N: int = 100000, seed: int = 1234):
+    """Utils.approxEllipsoid (src/Utils/qc.jl:50-67)"""
+    Y = sampleTrajs(net, x1min, x1max, N, seed)
     yc = Y.sum(axis=1) / N
     Yd = Y - yc[:, None]
     P = Yd @ Yd.T
