@@ -234,8 +234,8 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
  * and distributed by the host launcher (torch.distributed in bench.py --mode shard).  RCCL is dlopen'ed on
  * first use.  Independent SDPs need none of this (nnsdp_amd/parallel.py).  Every stopping / penalty / tolerance decision of
  * a sharded solve is taken from all-reduced numbers, so all ranks take it identically (including the time limit).
- * EXPERIMENTAL until a multi-rank run on hardware is on record (the build pool offers one GPU): covered by a one-rank
- * RCCL test on the GPU and a world-2 gloo test of the same partition and arithmetic. */
+ * Covered by a two-process run on one GPU through nnsdp_solver_set_comm_callback (below; RCCL refuses two ranks on one
+ * device) and a one-rank RCCL run; RCCL with more than one rank has not run yet (the build pool offers one GPU). */
 int nnsdp_comm_unique_id(char* id128);
 /* Host-only (no GPU, no RCCL): the PSD blocks the solver works on for (problem, options) and their partition over `nranks`
  * ranks - exactly what nnsdp_solver_set_comm uses.  Two-pass: n_blocks first (block_n = start = NULL), then
@@ -243,6 +243,12 @@ int nnsdp_comm_unique_id(char* id128);
 int nnsdp_shard_plan(const nnsdp_problem* p, const nnsdp_options* o, int32_t nranks, int32_t* n_blocks, int32_t* block_n,
                      int32_t* start);
 int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const char* id128);
+/* The same sharded mode over the CALLER's collective instead of RCCL (MPI.Allreduce! from the Julia side; gloo in the
+ * two-process GPU test): fn(user, buf, count) replaces the HOST buffer buf[count] by its element-wise sum over all ranks and
+ * returns 0.  The library stages the per-iteration exchange (and the 8 control numbers of a check iteration) through host
+ * memory for it; partition, kernels and the collective control decisions are those of nnsdp_solver_set_comm. */
+typedef int (*nnsdp_allreduce_fn)(void* user, double* buf, int64_t count);
+int nnsdp_solver_set_comm_callback(nnsdp_solver* s, int32_t nranks, int32_t rank, nnsdp_allreduce_fn fn, void* user);
 
 #ifdef __cplusplus
 }

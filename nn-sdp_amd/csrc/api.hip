@@ -326,6 +326,10 @@ struct nnsdp_solver {
   // clique-sharded mode (one rank per GPU, RCCL all-reduce of the consensus sum per iteration)
   int nranks = 1, rank = 0, k0 = 0, k1 = 0;
   Rccl::Comm comm = nullptr;
+  bool sharded = false;                // clique-sharded mode on (RCCL communicator or the caller's own all-reduce)
+  nnsdp_allreduce_fn ar_fn = nullptr;  // caller's sum-all-reduce over host buffers (nnsdp_solver_set_comm_callback)
+  void* ar_user = nullptr;
+  std::vector<double> ar_host;
   DBuf<int> d_sptr_own;
   DBuf<long long> d_soff_own;
   DBuf<double> hsum;
@@ -593,14 +597,19 @@ struct nnsdp_solver {
     else hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)S.ng * 64, kThreads)), dim3(kThreads), 0, s_, S.ng, ldm, Minv.p, qv.p, ww.p);
   }
 
-  void set_comm(int nr, int rk, const char* id128) {
-    if (nr < 1 || rk < 0 || rk >= nr || !id128) throw std::invalid_argument("bad communicator arguments");
+  void set_comm(int nr, int rk, const char* id128, nnsdp_allreduce_fn fn = nullptr, void* user = nullptr) {
+    if (nr < 1 || rk < 0 || rk >= nr || (!id128 && !fn)) throw std::invalid_argument("bad communicator arguments");
     if (iters_done != 0) throw std::invalid_argument("set_comm must be called before the first iteration");
+    if (sharded) throw std::invalid_argument("the solver already has a communicator");
     if (!big_idx.empty()) throw std::invalid_argument("clique-sharded mode needs every PSD block <= 128");
-    Rccl& R = Rccl::get();
-    Rccl::UniqueId uid;
-    std::memcpy(uid.internal, id128, 128);
-    R.check(R.CommInitRank(&comm, nr, uid, rk), "ncclCommInitRank");
+    if (fn) { ar_fn = fn; ar_user = user; }
+    else {
+      Rccl& R = Rccl::get();
+      Rccl::UniqueId uid;
+      std::memcpy(uid.internal, id128, 128);
+      R.check(R.CommInitRank(&comm, nr, uid, rk), "ncclCommInitRank");
+    }
+    sharded = true;
     nranks = nr; rank = rk;
     std::vector<int> start = shard_ranges(cn, nr);
     k0 = start[rk]; k1 = start[rk + 1];
@@ -620,6 +629,15 @@ struct nnsdp_solver {
   }
 
   void allreduce(double* buf, size_t count) {
+    if (ar_fn) {   // the caller's collective works on host memory: stage through a host buffer (stream order is kept)
+      ar_host.resize(count);
+      HIPCHK(hipMemcpyAsync(ar_host.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (ar_fn(ar_user, ar_host.data(), (int64_t)count) != 0) throw std::runtime_error("the caller's all-reduce reported a failure");
+      HIPCHK(hipMemcpyAsync(buf, ar_host.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      return;
+    }
     Rccl& R = Rccl::get();
     R.check(R.AllReduce(buf, buf, count, Rccl::kFloat64, Rccl::kSum, comm, st), "ncclAllReduce");
   }
@@ -656,7 +674,7 @@ struct nnsdp_solver {
     if (e0) HIPCHK(hipEventRecord(e0, st));
     enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
-    if (comm) {
+    if (sharded) {
       hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                          nu.p + ng, w.p + ng, 0, hsum.p);
       allreduce(hsum.p, NE);                      // the overlap-consensus exchange: one all-reduce per iteration
@@ -669,14 +687,14 @@ struct nnsdp_solver {
                        D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
     if (check) {
       HIPCHK(hipMemsetAsync(acc.p, 0, 8 * sizeof(double), st));
-      if (comm) {
+      if (sharded) {
         hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                            nu.p + ng, w.p + ng, 1, hsum.p);
         allreduce(hsum.p, NE);
       }
       hipLaunchKernelGGL(k_check_dual, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, ng, D.csr_ptr.p,
                          D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p,
-                         comm ? hsum.p : (const double*)nullptr);
+                         sharded ? hsum.p : (const double*)nullptr);
     }
     enqueue_minv(st);
     {
@@ -689,8 +707,8 @@ struct nnsdp_solver {
                          x.p, d_sigma(), acc.p);
     hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
                        d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr, coff[k0], coff[k1],
-                       (!comm || rank == 0) ? 1 : 0);
-    if (check && comm) {
+                       (!sharded || rank == 0) ? 1 : 0);
+    if (check && sharded) {
       // every stopping / adaptation decision is taken from these 8 numbers, so they must be bit-identical on all ranks:
       // [0..2] residual sums of the clique blocks live on their owners (multiplier block counted on rank 0 only);
       // [3..6] are computed redundantly everywhere (atomics: rounding differs between ranks) - rank 0's copy is used;
@@ -745,7 +763,7 @@ struct nnsdp_solver {
     while (left > 0) {
       bool can_warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
       static const bool no_graph = [] { const char* e = std::getenv("NNSDP_NO_GRAPH"); return e && std::atoi(e) != 0; }();   // diagnostic: eager launches only
-      if (!no_graph && !comm && big_idx.empty() && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
+      if (!no_graph && !sharded && big_idx.empty() && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
         build_graph(kGraphIters);
         HIPCHK(hipGraphLaunch(gexec, st));
         since_cold += kGraphIters; iters_done += kGraphIters; left -= kGraphIters;
@@ -843,7 +861,7 @@ struct nnsdp_solver {
         }
       }
     }
-    if (!advance_only && opt.max_time > 0 && (comm ? acc_host[7] > 0.0 : now_s() - t0 > opt.max_time)) return NNSDP_STATUS_TIME_LIMIT;
+    if (!advance_only && opt.max_time > 0 && (sharded ? acc_host[7] > 0.0 : now_s() - t0 > opt.max_time)) return NNSDP_STATUS_TIME_LIMIT;
     // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
     {
       double worst = std::max(last_pres, last_dres);
@@ -1165,7 +1183,7 @@ struct nnsdp_batch {
     if (!sv || count <= 0) throw std::invalid_argument("batch needs at least one solver");
     for (int i = 0; i < count; ++i) {
       if (!sv[i]) throw std::invalid_argument("null solver in batch");
-      if (sv[i]->comm) throw std::invalid_argument("clique-sharded solvers cannot be batched");
+      if (sv[i]->sharded) throw std::invalid_argument("clique-sharded solvers cannot be batched");
       if (!sv[i]->big_idx.empty()) throw std::invalid_argument("solvers with PSD blocks above 128 cannot be batched");
       if (sv[i]->opt.device != sv[0]->opt.device) throw std::invalid_argument("batched solvers must live on one device");
       if (sv[i]->opt.check_every != sv[0]->opt.check_every) throw std::invalid_argument("batched solvers must share check_every");
@@ -1749,6 +1767,14 @@ int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const c
   API_BEGIN
   if (!s) throw std::invalid_argument("null solver");
   s->set_comm(nranks, rank, id128);
+  API_END
+}
+
+int nnsdp_solver_set_comm_callback(nnsdp_solver* s, int32_t nranks, int32_t rank, nnsdp_allreduce_fn fn, void* user) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  if (!fn) throw std::invalid_argument("null all-reduce callback");
+  s->set_comm(nranks, rank, nullptr, fn, user);
   API_END
 }
 

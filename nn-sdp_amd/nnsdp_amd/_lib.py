@@ -57,6 +57,8 @@ class Result(C.Structure):
 
 
 # every symbol include/nnsdp.h declares: (name, restype, argtypes)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)   # nnsdp_allreduce_fn
+
 SYMBOLS = [
     ("nnsdp_version", C.c_int, []),
     ("nnsdp_last_error", C.c_char_p, []),
@@ -89,6 +91,7 @@ SYMBOLS = [
     ("nnsdp_comm_unique_id", C.c_int, [C.c_char_p]),
     ("nnsdp_shard_plan", C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("nnsdp_solver_set_comm", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
+    ("nnsdp_solver_set_comm_callback", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]),
 ]
 
 _lib = None

@@ -417,6 +417,20 @@ class Solver:
         assert len(unique_id) == 128
         _lib.check(self.lib.nnsdp_solver_set_comm(self.h, int(nranks), int(rank), unique_id))
 
+    def set_comm_callback(self, nranks: int, rank: int, allreduce) -> None:
+        """clique-sharded mode over the caller's own collective: allreduce(a) sums the float64 numpy array `a` over all ranks
+        IN PLACE (e.g. torch.distributed.all_reduce(torch.from_numpy(a)) on a gloo group)."""
+        def _cb(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                return 0
+            except Exception:      # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ar_cb = _lib.ALLREDUCE_FN(_cb)       # keep the trampoline alive as long as the handle
+        _lib.check(self.lib.nnsdp_solver_set_comm_callback(self.h, int(nranks), int(rank), self._ar_cb, None))
+
     def iterate_async(self, iters: int) -> None:
         _lib.check(self.lib.nnsdp_solver_iterate_async(self.h, int(iters)))
 

@@ -1,0 +1,55 @@
+"""Worker of tests/test_sharded_two_ranks.py: one rank of a clique-sharded solve on the GPU, the per-iteration exchange carried
+by gloo through nnsdp_solver_set_comm_callback (RCCL refuses two ranks on one device, and the test box has one).
+usage: python tests/shard_worker.py <rank> <world> <port> <fixture> <beta> <out.json>"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nn-sdp_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world, port, name, beta, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), sys.argv[6]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import helpers
+    import nnsdp_amd as na
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    calls = [0]
+
+    def allreduce(a):
+        calls[0] += 1
+        dist.all_reduce(torch.from_numpy(a))      # in place on the library's host buffer
+
+    q = helpers.product_query(helpers.load_problem(name, beta))
+    res = {"rank": rank}
+    # (a) exactly 300 plain iterations, then one check iteration
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()))
+    s.set_comm_callback(world, rank, allreduce)
+    s.iterate(300)
+    res["after_300"] = list(s.residuals())
+    s.close()
+    # (b) a whole solve: every stopping / penalty / tolerance decision is collective
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
+    s.set_comm_callback(world, rank, allreduce)
+    sol = s.run()
+    res["solve"] = dict(status=sol.termination_status, iters=int(sol.summary["iters"]), rho=float(sol.objective_value),
+                        admm=float(sol.summary["objective_admm"]), pres=float(sol.summary["pres"]), dres=float(sol.summary["dres"]),
+                        lambda_max=float(sol.summary["lambda_max"]),
+                        gamma=np.concatenate([sol.values[k] for k in ("γin", "γout", "γac1", "γac2")]).tolist())
+    s.close()
+    res["allreduce_calls"] = calls[0]
+    bn, st = na.shardPlan(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp()), world)
+    res["blocks_owned"] = [int(st[rank]), int(st[rank + 1])]
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(out, "w") as fh:
+        json.dump(res, fh)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""The product's clique-sharded mode with TWO ranks on the GPU ("no process group larger than 1 has ever driven
+nnsdp_solver_set_comm").  RCCL refuses two ranks on one device and the test box has one, so the two processes exchange through
+gloo via nnsdp_solver_set_comm_callback; partition, owned-source gather, the kernels, the staging of the exchange and the
+collective control decisions are the code RCCL mode runs (the RCCL call itself: test_clique_sharded_mode_single_rank_rccl)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+import nnsdp_amd as na
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.parametrize("name,beta", [("W10-D10", 0), ("W40-D20", 0)])
+def test_two_rank_sharded_solve_matches_the_serial_solve(name, beta, tmp_path):
+    port = _free_port()
+    worker = os.path.join(helpers.ROOT, "tests", "shard_worker.py")
+    outs = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, name, str(beta), outs[r]]) for r in range(2)]
+    # the serial solves run in this process meanwhile (3 processes on the card)
+    q = helpers.product_query(helpers.load_problem(name, beta))
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()))
+    s.iterate(300)
+    ref300 = s.residuals()
+    s.close()
+    ref = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = (json.load(open(o)) for o in outs)
+    # (a) 300 plain iterations: the same iterate as the serial run (the consensus sum is associated differently: 1e-9)
+    for r in (r0, r1):
+        assert np.allclose(r["after_300"], ref300, rtol=1e-8, atol=1e-12), (r["after_300"], ref300)
+    assert r0["after_300"] == r1["after_300"]                     # the control numbers are bit-identical on both ranks
+    # (b) whole solve: both ranks take every decision identically and land on the serial certificate
+    a, b = r0["solve"], r1["solve"]
+    assert a["status"] == b["status"] == ref.termination_status == "OPTIMAL"
+    assert a["iters"] == b["iters"]
+    assert np.array_equal(np.array(a["gamma"]), np.array(b["gamma"]))
+    assert abs(a["admm"] - ref.summary["objective_admm"]) <= 1e-4 * abs(ref.summary["objective_admm"])
+    assert abs(a["rho"] - ref.objective_value) <= 1e-3 * abs(ref.objective_value)
+    assert a["lambda_max"] <= 1e-6 and min(a["gamma"]) >= 0.0
+    assert r0["blocks_owned"][1] == r1["blocks_owned"][0] and r0["blocks_owned"][0] == 0
+    assert r0["allreduce_calls"] == r1["allreduce_calls"] >= a["iters"]
