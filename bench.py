@@ -252,7 +252,7 @@ def main():
     if rank == 0 and world == 1 and args.cert_seconds > 0 and not shard:
         # wall-clock to certificate on fresh solves (setup + ADMM to eps_rel = 1e-6 + feasibility polish)
         out["time_to_cert"] = {}
-        for mode in (na.SingleDecomp(), na.DoubleDecomp()):
+        for mode in (na.SingleDecomp(), na.DoubleDecomp(), na.PathDecomp()):   # Single / Double: chordal_sdp.jl:8-9; Path: finer cliques, an extension
             for rule, kw in (("residual_1e-6", dict(eps_rel=1e-6)), ("certified_gap_1e-3", dict(eps_rel=1e-6, cert_tol=1e-3))):
                 o2 = na.AdmmSdpOptions(decomp_mode=mode, max_iters=500000, max_time=args.cert_seconds, **kw)
                 t1 = time.perf_counter()
