@@ -845,8 +845,16 @@ struct nnsdp_solver {
     if (!advance_only && last_pres <= opt.eps_rel && last_dres <= opt.eps_rel) return NNSDP_STATUS_OPTIMAL;
     // optional early stop on the CERTIFIED objective: the polished point is exactly feasible, so once it
     // is within cert_tol of the ADMM estimate of the optimum the certificate is as good as it gets
-    if (!advance_only && opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= 1e-3) {
-      next_cert = std::max<long long>(iters_done + 250, iters_done * 5 / 4);
+    // The polish costs about 75 iterations (10 ms at W40-D20), so it only runs once the free part of the test - the ADMM primal
+    // and dual estimates agree within cert_tol - holds, and then at most every 10 % of the iterations done
+    // (profiles/r02_polish_trace_*.log, tools/cert_rule_sim.py: the estimates oscillate by +-1e-3 long after the polished value is good enough).
+    // The ADMM estimates are only as good as the residuals (they oscillate around the optimum with an amplitude of a few times
+    // max(pres, dres)), so they are trusted at the cert_tol level once the residuals are a tenth of it: over the traced solves
+    // every check point that passes all three conditions is within cert_tol of the true optimum (max 9.3e-4 for 1e-3), without
+    // the residual condition one is 1.9e-3 off.
+    if (!advance_only && opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= std::min(1e-3, 0.1 * opt.cert_tol) &&
+        std::fabs(last_pobj - last_dobj) <= opt.cert_tol * std::max(std::fabs(last_pobj), std::fabs(last_dobj))) {
+      next_cert = std::max<long long>(iters_done + 100, iters_done * 11 / 10);
       hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
       HIPCHK(hipStreamSynchronize(st));
       std::vector<double> gp = gs.download();

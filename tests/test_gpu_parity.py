@@ -317,18 +317,27 @@ def test_polished_certificate_is_feasible(name, beta, iters):
     assert s.objective_value - ra <= 2e-3 * abs(ra), (s.objective_value, ra)
 
 
-def test_certified_gap_stopping_rule():
-    """cert_tol: stop as soon as the polished, exactly feasible objective is within 1e-3 of the ADMM estimates;
-    the result must be a valid certificate whose objective upper-bounds the converged optimum by <= 2e-3."""
-    d = helpers.load_problem("W10-D10", 0)
-    q = helpers.product_query(d)
-    full = na.runQuery(q, na.AdmmSdpOptions(max_iters=20000, decomp_mode=na.DoubleDecomp()))
-    fast = na.runQuery(q, na.AdmmSdpOptions(max_iters=20000, decomp_mode=na.DoubleDecomp(), cert_tol=1e-3))
-    assert fast.termination_status == "OPTIMAL" and fast.summary["iters"] < full.summary["iters"]
-    assert fast.summary["lambda_max"] <= 1e-6
-    opt = full.summary["objective_admm"]
+@pytest.mark.parametrize("name,beta,mode", [("W10-D10", 0, "double"), ("W40-D20", 0, "double"), ("W40-D20", 0, "path"), ("W40-D20", 2, "path")])
+def test_certified_gap_stopping_rule(name, beta, mode):
+    """cert_tol: stop as soon as the polished, exactly feasible objective is within 1e-3 of the ADMM estimates, those being trusted
+    once the residuals are below a tenth of cert_tol.  The result is a valid certificate whose objective upper-bounds the
+    converged optimum (oracle fixture where there is one) by <= 1e-3 - the epsilon of SURVEY section 8d."""
+    import json, os
+    q = helpers.product_query(helpers.load_problem(name, beta))
+    dm = na.DoubleDecomp() if mode == "double" else na.PathDecomp()
+    fast = na.runQuery(q, na.AdmmSdpOptions(max_iters=400000, decomp_mode=dm, cert_tol=1e-3, max_time=100))
+    key = f"{name}_b{beta}"
+    fixture = json.load(open(os.path.join(helpers.GOLDEN, "oracle_optimum.json")))
+    if key in fixture:
+        opt = fixture[key]["rho"]
+    else:
+        full = na.runQuery(q, na.AdmmSdpOptions(max_iters=400000, decomp_mode=dm, max_time=100))
+        assert fast.summary["iters"] < full.summary["iters"]
+        opt = full.summary["objective_admm"]
+    assert fast.termination_status == "OPTIMAL"
+    assert fast.summary["lambda_max"] <= 1e-6 and min(np.min(fast.values[k]) for k in ("γin", "γout", "γac1", "γac2")) >= 0.0
     assert fast.objective_value >= opt * (1 - 1e-4)
-    assert fast.objective_value - opt <= 2e-3 * opt
+    assert fast.objective_value - opt <= 1e-3 * opt, (fast.objective_value, opt, fast.summary["iters"])
 
 
 def test_full_size_solver_invariants_w40_d20():
