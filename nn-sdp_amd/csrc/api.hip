@@ -675,12 +675,12 @@ struct nnsdp_solver {
     enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
     if (sharded) {
-      hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
+      hipLaunchKernelGGL(k_gather_h, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                          nu.p + ng, w.p + ng, 0, hsum.p);
       allreduce(hsum.p, NE);                      // the overlap-consensus exchange: one all-reduce per iteration
       hipLaunchKernelGGL(k_finish_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, hsum.p, D.z0.p, D.Dinv.p, d_sigma(), g.p);
     } else {
-      hipLaunchKernelGGL(k_gather_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
+      hipLaunchKernelGGL(k_gather_g, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
                          nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p);
     }
     hipLaunchKernelGGL(k_spmv_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, D.csc_ptr.p, D.csc_row.p,
@@ -688,7 +688,7 @@ struct nnsdp_solver {
     if (check) {
       HIPCHK(hipMemsetAsync(acc.p, 0, 8 * sizeof(double), st));
       if (sharded) {
-        hipLaunchKernelGGL(k_gather_h, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
+        hipLaunchKernelGGL(k_gather_h, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                            nu.p + ng, w.p + ng, 1, hsum.p);
         allreduce(hsum.p, NE);
       }
@@ -1245,7 +1245,7 @@ struct nnsdp_batch {
       q.warm = 0; pc.push_back(q);
       for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));
       nmax = std::max(nmax, s->nmax);
-      gx_gather = std::max(gx_gather, cdiv(a.NE, kThreads));
+      gx_gather = std::max(gx_gather, cdiv((long long)a.NE * kGatherLanes, kThreads));
       gx_at = std::max(gx_at, cdiv((long long)a.ng * 64, kThreads));
       gx_gemv = gx_at;
       gx_ax = std::max(gx_ax, cdiv((long long)a.NE * kRowLanes, kThreads));

@@ -1418,16 +1418,27 @@ __global__ __launch_bounds__(kThreads) void k_spmv_At_b(const IterArgs* __restri
   spmv_At_body(blockIdx.x, a.ng, a.csc_ptr, a.csc_row, a.csc_val, a.g, a.nu, a.c, a.kappa, a.p, a.qv);
 }
 
-// g[e] = Dinv[e] (z0[e] / sigma + wgt * sum_src (2 w - nu)[src]); one thread per pattern entry
+// g[e] = Dinv[e] (z0[e] / sigma + wgt * sum_src (2 w - nu)[src]); kGatherLanes lanes per pattern entry: the entries of the
+// block every clique shares ((x_K, a): 19 sources at W40-D20, 39 at W40-D40) are a dependent chain of 19-39 indirect loads for
+// ONE thread otherwise, and the launch lasts as long as that chain (11.1 us for 27.6 k entries)
+static constexpr int kGatherLanes = 8;
+__device__ __forceinline__ double gather_sum(double s) {   // sum over the kGatherLanes lanes of an entry, valid in all of them
+#pragma unroll
+  for (int o = 1; o < kGatherLanes; o <<= 1) s += __shfl_xor(s, o, kGatherLanes);
+  return s;
+}
 __device__ __forceinline__ void gather_g_body(const int bid, int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
                                                         const unsigned char* __restrict__ isdiag,
                                                         const double* __restrict__ nuk, const double* __restrict__ wk,
                                                         const double* __restrict__ z0, const double* __restrict__ Dinv,
                                                         const double* __restrict__ sigma, double* __restrict__ g) {
-  int e = bid * kThreads + threadIdx.x;
-  if (e >= NE) return;
+  const int t = bid * kThreads + threadIdx.x;
+  const int e = t / kGatherLanes, sub = t % kGatherLanes;
+  if (e >= NE) return;   // (the lanes of one entry leave together)
   double s = 0.0;
-  for (int q = sptr[e]; q < sptr[e + 1]; ++q) { long long o = soff[q]; s += 2.0 * wk[o] - nuk[o]; }
+  for (int q = sptr[e] + sub; q < sptr[e + 1]; q += kGatherLanes) { long long o = soff[q]; s += 2.0 * wk[o] - nuk[o]; }
+  s = gather_sum(s);
+  if (sub != 0) return;
   if (!isdiag[e]) s *= kSqrt2;
   g[e] = Dinv[e] * (z0[e] / (*sigma) + s);
 }
@@ -1438,7 +1449,7 @@ __global__ __launch_bounds__(kThreads) void k_gather_g(int NE, const int* __rest
                                                         const double* __restrict__ sigma, double* __restrict__ g) { gather_g_body(blockIdx.x, NE, sptr, soff, isdiag, nuk, wk, z0, Dinv, sigma, g); }
 __global__ __launch_bounds__(kThreads) void k_gather_g_b(const IterArgs* __restrict__ A) {
   const IterArgs a = A[blockIdx.y];
-  if ((long long)blockIdx.x * kThreads >= (long long)a.NE) return;
+  if ((long long)blockIdx.x * kThreads >= (long long)a.NE * kGatherLanes) return;
   gather_g_body(blockIdx.x, a.NE, a.sptr, a.soff, a.isdiag, a.nu + a.ng, a.w + a.ng, a.z0, a.Dinv, a.sigma, a.g);
 }
 
@@ -1447,13 +1458,16 @@ __global__ __launch_bounds__(kThreads) void k_gather_g_b(const IterArgs* __restr
 __global__ __launch_bounds__(kThreads) void k_gather_h(int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
                                                         const unsigned char* __restrict__ isdiag, const double* __restrict__ nuk,
                                                         const double* __restrict__ wk, int dual, double* __restrict__ h) {
-  int e = blockIdx.x * kThreads + threadIdx.x;
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  const int e = t / kGatherLanes, sub = t % kGatherLanes;
   if (e >= NE) return;
   double s = 0.0;
-  for (int q = sptr[e]; q < sptr[e + 1]; ++q) {
+  for (int q = sptr[e] + sub; q < sptr[e + 1]; q += kGatherLanes) {
     long long o = soff[q];
     s += dual ? nuk[o] - wk[o] : 2.0 * wk[o] - nuk[o];
   }
+  s = gather_sum(s);
+  if (sub != 0) return;
   if (!isdiag[e]) s *= kSqrt2;
   h[e] = s;
 }
