@@ -692,7 +692,8 @@ struct nnsdp_solver {
                            nu.p + ng, w.p + ng, 1, hsum.p);
         allreduce(hsum.p, NE);
       }
-      hipLaunchKernelGGL(k_check_dual, dim3(cdiv((long long)NE * 16, kThreads)), dim3(kThreads), 0, st, NE, ng, D.csr_ptr.p,
+      const int nreg_cd = cdiv((long long)NE * 16, kThreads);
+      hipLaunchKernelGGL(k_check_dual, dim3(nreg_cd + nlong), dim3(kThreads), 0, st, NE, ng, nreg_cd, nlong, d_long.p, D.csr_ptr.p,
                          D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p,
                          sharded ? hsum.p : (const double*)nullptr);
     }

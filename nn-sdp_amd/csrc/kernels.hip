@@ -1712,31 +1712,51 @@ __global__ __launch_bounds__(kThreads) void k_update_nu_b(const IterArgs* __rest
 
 // check iteration, dual side: t[e] = (K'y)[e] = sum_g A[e,g] ys[g] + wgt * sum_src y_k[src],
 // y = sigma (nu - w).  acc[3] += |t - z0|^2, acc[4] += |t|^2; 16 lanes per entry.
-__global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, const int* __restrict__ ptr, const int* __restrict__ col,
+__global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, int nreg, int nlong, const int* __restrict__ longrows,
+                                                          const int* __restrict__ ptr, const int* __restrict__ col,
                                                           const double* __restrict__ val, const int* __restrict__ sptr,
                                                           const long long* __restrict__ soff, const unsigned char* __restrict__ isdiag,
                                                           const double* __restrict__ nu, const double* __restrict__ w,
                                                           const double* __restrict__ z0, const double* __restrict__ sigma,
                                                           double* __restrict__ acc, const double* __restrict__ hsum) {
-  // hsum != null (clique-sharded mode): the clique part of K'y/sigma, already summed over ranks
+  // hsum != null (clique-sharded mode): the clique part of K'y/sigma, already summed over ranks.
+  // Blocks [0, nreg): 16 lanes per entry, rows with more than kLongRow nonzeros skipped; blocks [nreg, nreg + nlong): one
+  // workgroup per long row (the (a,a) entry meets every multiplier: 3 203 nonzeros at W40-D20, 200 steps for 16 lanes)
   __shared__ double red[8];
-  int e = (blockIdx.x * kThreads + threadIdx.x) >> 4;
-  int sub = threadIdx.x & 15;
   double sg = *sigma;
-  double s = 0.0, h = 0.0;
-  if (e < NE) {
-    for (int q = ptr[e] + sub; q < ptr[e + 1]; q += 16) { double v = nu[col[q]]; s += val[q] * (v < 0.0 ? v : 0.0); }
-    if (hsum) { if (sub == 0) h = hsum[e]; }
+  double d2 = 0.0, t2 = 0.0;
+  if ((int)blockIdx.x < nreg) {
+    int e = (blockIdx.x * kThreads + threadIdx.x) >> 4;
+    int sub = threadIdx.x & 15;
+    double s = 0.0, h = 0.0;
+    const bool mine = e < NE && ptr[e + 1] - ptr[e] <= kLongRow;
+    if (mine) {
+      for (int q = ptr[e] + sub; q < ptr[e + 1]; q += 16) { double v = nu[col[q]]; s += val[q] * (v < 0.0 ? v : 0.0); }
+      if (hsum) { if (sub == 0) h = hsum[e]; }
+      else {
+        for (int q = sptr[e] + sub; q < sptr[e + 1]; q += 16) { long long o = soff[q]; h += nu[ng + o] - w[ng + o]; }
+        if (!isdiag[e]) h *= kSqrt2;
+      }
+    }
+    s += h;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
+    if (mine && sub == 0) { double t = sg * s; double d = t - z0[e]; d2 = d * d; t2 = t * t; }
+  } else {
+    const int b = blockIdx.x - nreg;
+    if (b >= nlong) return;
+    const int e = longrows[b];
+    double s = 0.0, h = 0.0;
+    for (int q = ptr[e] + threadIdx.x; q < ptr[e + 1]; q += kThreads) { double v = nu[col[q]]; s += val[q] * (v < 0.0 ? v : 0.0); }
+    if (hsum) { if (threadIdx.x == 0) h = hsum[e]; }
     else {
-      for (int q = sptr[e] + sub; q < sptr[e + 1]; q += 16) { long long o = soff[q]; h += nu[ng + o] - w[ng + o]; }
+      for (int q = sptr[e] + threadIdx.x; q < sptr[e + 1]; q += kThreads) { long long o = soff[q]; h += nu[ng + o] - w[ng + o]; }
       if (!isdiag[e]) h *= kSqrt2;
     }
+    s = block_sum(s + h, red);
+    if (threadIdx.x == 0) { double t = sg * s; double d = t - z0[e]; d2 = d * d; t2 = t * t; }
+    __syncthreads();
   }
-  s += h;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 16);
-  double d2 = 0.0, t2 = 0.0;
-  if (e < NE && sub == 0) { double t = sg * s; double d = t - z0[e]; d2 = d * d; t2 = t * t; }
   d2 = block_sum(d2, red);
   t2 = block_sum(t2, red + 4);
   if (threadIdx.x == 0) { atomicAdd(&acc[3], d2); atomicAdd(&acc[4], t2); }
