@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(64) void k_symv_reduce_b(const IterArgs* __restrict
 
 // x[e] = g[e] - Dinv[e] * sum_g A[e,g] ww[g]; 4 lanes per pattern entry (W40-D20: 27.6 k rows, 60 % of them with no
 // multiplier at all and 37 % with one; only 2 880 rows carry more than 16 nonzeros)
-static constexpr int kRowLanes = 4;
+static constexpr int kRowLanes = 8;
 static constexpr int kLongRow = 256;   // rows of A with more nonzeros go to the block-per-row kernel
 __device__ __forceinline__ void spmv_A_x_body(const int bid, int NE, const int* __restrict__ ptr, const int* __restrict__ col,
                                                         const double* __restrict__ val, const double* __restrict__ ww,
