@@ -619,8 +619,10 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
             if (!dg) dst[1] = t11 + pr.x * t01;
           };
           const int it0 = ik[sg][0];
-          double2 pr0 = make_double2(0.0, 0.0), pq0 = pr0;
-          double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+          // (deliberately not initialised: they are only read under the same it0 >= 0 below, and eight v_mov_b64 of zeros per
+          // wave and round are 10 % of the round's VALU issue slots)
+          double2 pr0, pq0;
+          double a00, a01, a10, a11;
           if (it0 >= 0) {
             const double* src = Ain + eb[sg][0];
             pr0 = *reinterpret_cast<const double2*>(ttr + 2 * (it0 >> 8));
