@@ -1621,17 +1621,19 @@ int nnsdp_eval_network(int32_t K, const int32_t* xdims, const double* M, int32_t
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nnsdp::k_forward_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   nnsdp::FwdArgs a;
   a.K = K; a.xdims = dxd.p; a.moff = dmo.p; a.M = dM.p; a.X = dX.p; a.Y = dY.p; a.N = N; a.activ = activ; a.wp = wp;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, nullptr));
+  struct Events {   // destroyed on every path out of this function, HIPCHK throws
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  } ev;
+  HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
+  HIPCHK(hipEventRecord(ev.e0, nullptr));
   hipLaunchKernelGGL(nnsdp::k_forward_mfma, dim3((unsigned)((N + 15) / 16)), dim3(64), lds, nullptr, a);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e1, nullptr));
-  HIPCHK(hipEventSynchronize(e1));
+  HIPCHK(hipEventRecord(ev.e1, nullptr));
+  HIPCHK(hipEventSynchronize(ev.e1));
   float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   if (kernel_ms) *kernel_ms = ms;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   HIPCHK(hipMemcpy(Y, dY.p, (size_t)xd[K] * N * sizeof(double), hipMemcpyDeviceToHost));
   API_END
 }
