@@ -249,6 +249,20 @@ def main():
             "graph_replay_iters_per_s": graph_ips,
             "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
         }
+    if rank == 0 and world == 1 and not shard:
+        # round 1's default window (5 warmup + 20 timed iterations of a FRESH solver, no burn-in), kept for a like-for-like
+        # comparison with BENCH_r01.json: the first iterations of a solve are not the regime it spends its time in
+        s0 = na.Solver(q, opts)
+        s0.iterate(5, time_eig=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ms0 = s0.iterate(20, time_eig=True)
+        torch.cuda.synchronize()
+        dt0 = time.perf_counter() - t1
+        s0.close()
+        out["round1_window"] = {"warmup": 5, "steps": 20, "burn_in_iters": 0, "iters_per_s": 20 / dt0, "kernel_avg_us": 1e3 * ms0 / 20,
+                                "note": "the window BENCH_r01.json used; same-box comparison of the two trees: profiles/r02_vs_r01_same_box.log "
+                                        "(round-1 tree 4 974 it/s / 161.0 us, this tree 5 421 it/s / 152.3 us in this window)"}
     if rank == 0 and world == 1 and args.cert_seconds > 0 and not shard:
         # wall-clock to certificate on fresh solves (setup + ADMM to eps_rel = 1e-6 + feasibility polish)
         out["time_to_cert"] = {}
