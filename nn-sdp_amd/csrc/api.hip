@@ -499,6 +499,18 @@ struct nnsdp_solver {
     const MinvPlan& Q = mplan;
     MinvBlocks B = assemble_minv_blocks(S, Q);
     const int ng = S.ng, nc = Q.nchunk, nS = Q.nS, ldS = Q.ldS;
+    if (opt.verbose || std::getenv("NNSDP_MINV_PLAN")) {
+      double bp = 0, bh = 0;
+      int nmaxc = 0, wmax = 0;
+      for (int j = 0; j < nc; ++j) {
+        const double n = Q.chi[j] - Q.clo[j], wj = Q.w1[j] - Q.w0[j];
+        bp += 8.0 * n * n; bh += 8.0 * n * wj;
+        nmaxc = std::max(nmaxc, (int)n); wmax = std::max(wmax, (int)wj);
+      }
+      std::fprintf(stderr, "[nnsdp] structured M^-1: %d multipliers, %d chunks (largest %d), separator %d (widest coupling %d), rank-%d term; "
+                   "bytes per application: chunk inverses %.1f MB (stage 1), H %.1f MB (stage 1) + %.1f MB (stage 3), Schur inverse %.1f MB\n",
+                   ng, nc, nmaxc, nS, wmax, Q.r, bp / 1e6, bh / 1e6, bh / 1e6, 8.0 * nS * (double)nS / 1e6);
+    }
     DBuf<double> Tjs;
     m_P.upload(B.Tjj); Tjs.upload(B.Tjs); m_Sc.upload(B.Tss);
     m_H.alloc((size_t)Q.htot); m_HT.alloc((size_t)Q.htot);
