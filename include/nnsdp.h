@@ -162,6 +162,10 @@ int nnsdp_solver_residuals(nnsdp_solver* s, double* pres, double* dres, double* 
 /* test / diagnostic entry: out = M^-1 q for a full-length multiplier vector q (entries of dropped multipliers are ignored and
  * returned as 0), through whichever form the handle uses; *structured (may be NULL) tells which, *operand_bytes its size */
 int nnsdp_solver_apply_minv(nnsdp_solver* s, const double* q, double* out, int32_t* structured, int64_t* operand_bytes);
+/* test / diagnostic entry: the multiplier block of the solver's fixed-point variable nu (solver coordinates and scaling), one
+ * entry per multiplier of the problem (dropped multipliers 0).  In clique-sharded mode this block is replicated; the two-rank
+ * test compares it bit for bit between ranks. */
+int nnsdp_solver_raw_multipliers(nnsdp_solver* s, double* out);
 /* iterate until converged / limits; fills r like nnsdp_solve */
 int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r);
 int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r);

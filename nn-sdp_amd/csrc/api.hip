@@ -173,7 +173,12 @@ struct Rccl {
 
 struct RocHandle {
   rocblas_handle h = nullptr;
-  RocHandle() { RBCHK(rocblas_create_handle(&h)); }
+  RocHandle() {
+    RBCHK(rocblas_create_handle(&h));
+    // reproducible library results: no atomics-based (split-K) accumulation inside rocBLAS / rocSOLVER.  M^-1, the certificate
+    // polish and the eigmax check are then the same bits run to run and rank to rank on one GPU model
+    RBCHK(rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed));
+  }
   ~RocHandle() { if (h) rocblas_destroy_handle(h); }
 };
 
@@ -298,7 +303,10 @@ struct nnsdp_solver {
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
-  DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc, gs;
+  DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc /* 8 control numbers | ng multipliers (sharded resync) */, gs;
+  DBuf<double> accp;                    // per-workgroup partial sums of the residual quantities: [7][acc_stride]
+  int acc_stride = 0, nb_upd = 0, nb_dual = 0, nb_obj = 0;
+  bool big_fail = false;                // a library eigensolve of a block above the LDS kernel's range reported info != 0
   // structured M^-1 (minv.hpp): used instead of the dense inverse for large multiplier counts
   bool minv_structured = false;
   MinvPlan mplan;
@@ -402,7 +410,8 @@ struct nnsdp_solver {
       for (int k : small_idx) { cs.push_back(cn[k]); os.push_back(coff[k]); }
       if (cs.empty()) { cs.push_back(1); os.push_back(0); }
       d_cn_s.upload(cs); d_coff_s.upload(os);
-      big_A.alloc((size_t)nmax * nmax); big_T.alloc((size_t)nmax * nmax); big_D.alloc(nmax); big_E.alloc(nmax); big_info.alloc(1);
+      big_A.alloc((size_t)nmax * nmax); big_T.alloc((size_t)nmax * nmax); big_D.alloc(nmax); big_E.alloc(nmax);
+      big_info.alloc(big_idx.size()); big_info.zero();
     }
     const int nsm = std::max(nmax_small, 1);
     proj_alg = proj_algorithm(nsm);
@@ -476,7 +485,12 @@ struct nnsdp_solver {
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
     x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
-    scal.alloc(4); acc.alloc(8);
+    scal.alloc(4); acc.alloc(8 + (size_t)ng); acc.zero();
+    nb_upd = cdiv(ng + nmat, kThreads);
+    nb_dual = cdiv((long long)S.NE * 16, kThreads) + nlong;
+    nb_obj = cdiv(std::max(ng, S.NE), kThreads);
+    acc_stride = std::max({nb_upd, nb_dual, nb_obj});
+    accp.alloc(7 * (size_t)acc_stride);
     nu.zero(); w.zero(); Vg.zero(); x.zero(); g.zero(); qv.zero();
     {
       std::vector<double> s0(ng);
@@ -654,6 +668,22 @@ struct nnsdp_solver {
     R.check(R.AllReduce(buf, buf, count, Rccl::kFloat64, Rccl::kSum, comm, st), "ncclAllReduce");
   }
 
+  // sum-all-reduce of a small HOST vector (rank 0's certificate / stop flag travelling to every rank)
+  DBuf<double> bc_dev;
+  void allreduce_host(std::vector<double>& v) {
+    if (!sharded || v.empty()) return;
+    if (ar_fn) {
+      if (ar_fn(ar_user, v.data(), (int64_t)v.size()) != 0) throw std::runtime_error("the caller's all-reduce reported a failure");
+      return;
+    }
+    if (bc_dev.n < v.size()) bc_dev.alloc(v.size());
+    HIPCHK(hipMemcpyAsync(bc_dev.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    allreduce(bc_dev.p, v.size());
+    HIPCHK(hipMemcpyAsync(v.data(), bc_dev.p, v.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  bool lead() const { return !sharded || rank == 0; }
+
   void enqueue_proj(bool warm) {
     ProjArgs a;
     a.cn = d_cn.p + k0; a.coff = d_coff.p + k0; a.eoff = nullptr;
@@ -670,11 +700,12 @@ struct nnsdp_solver {
       a.cn = d_cn_s.p; a.coff = d_coff_s.p;
       nnsdp::launch_proj(a, (int)small_idx.size(), nmax_small, v_lds, lds_bytes, st, proj_alg);
     }
-    for (int k : big_idx) {
+    for (size_t bi = 0; bi < big_idx.size(); ++bi) {
+      const int k = big_idx[bi];
       const int n = cn[k];
       double* nuk = nu.p + S.ng + coff[k];
       double* wk = w.p + S.ng + coff[k];
-      project_big_block(roc->h, st, n, nuk, wk, big_A.p, big_T.p, big_D.p, big_E.p, big_info.p);
+      project_big_block(roc->h, st, n, nuk, wk, big_A.p, big_T.p, big_D.p, big_E.p, big_info.p + bi);
       hipLaunchKernelGGL(k_big_rescale, dim3(cdiv((long long)n * n, 256)), dim3(256), 0, st, (long long)n * n, wk, nuk, d_kappa());
     }
     HIPCHK(hipGetLastError());
@@ -698,16 +729,15 @@ struct nnsdp_solver {
     hipLaunchKernelGGL(k_spmv_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, D.csc_ptr.p, D.csc_row.p,
                        D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
     if (check) {
-      HIPCHK(hipMemsetAsync(acc.p, 0, 8 * sizeof(double), st));
       if (sharded) {
         hipLaunchKernelGGL(k_gather_h, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
                            nu.p + ng, w.p + ng, 1, hsum.p);
         allreduce(hsum.p, NE);
       }
-      const int nreg_cd = cdiv((long long)NE * 16, kThreads);
-      hipLaunchKernelGGL(k_check_dual, dim3(nreg_cd + nlong), dim3(kThreads), 0, st, NE, ng, nreg_cd, nlong, d_long.p, D.csr_ptr.p,
-                         D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), acc.p,
-                         sharded ? hsum.p : (const double*)nullptr);
+      const int nreg_cd = nb_dual - nlong;
+      hipLaunchKernelGGL(k_check_dual, dim3(nb_dual), dim3(kThreads), 0, st, NE, ng, nreg_cd, nlong, d_long.p, D.csr_ptr.p,
+                         D.csr_col.p, D.csr_val.p, d_sptr.p, d_soff.p, d_isdiag.p, nu.p, w.p, D.z0.p, d_sigma(), accp.p,
+                         sharded ? hsum.p : (const double*)nullptr, acc_stride);
     }
     enqueue_minv(st);
     {
@@ -716,21 +746,28 @@ struct nnsdp_solver {
                          D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p);
     }
     if (check)
-      hipLaunchKernelGGL(k_check_obj, dim3(cdiv(std::max(ng, NE), kThreads)), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p,
-                         x.p, d_sigma(), acc.p);
-    hipLaunchKernelGGL(k_update_nu, dim3(cdiv(ng + nmat, kThreads)), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
-                       d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? acc.p : (double*)nullptr, coff[k0], coff[k1],
-                       (!sharded || rank == 0) ? 1 : 0);
+      hipLaunchKernelGGL(k_check_obj, dim3(nb_obj), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p, x.p, d_sigma(), accp.p, acc_stride);
+    hipLaunchKernelGGL(k_update_nu, dim3(nb_upd), dim3(kThreads), 0, st, ng, nmat, p.p, ww.p, D.c.p, x.p,
+                       d_gidx.p, nu.p, w.p, opt.alpha, d_kappa(), check ? accp.p : (double*)nullptr, coff[k0], coff[k1],
+                       (!sharded || rank == 0) ? 1 : 0, acc_stride);
+    if (check)   // fixed-order second stage of the residual sums (no atomics on the way to a stopping decision)
+      hipLaunchKernelGGL(k_acc_reduce, dim3(1), dim3(kThreads), 0, st, accp.p, acc_stride, nb_upd, nb_dual, nb_obj, acc.p);
     if (check && sharded) {
       // every stopping / adaptation decision is taken from these 8 numbers, so they must be bit-identical on all ranks:
       // [0..2] residual sums of the clique blocks live on their owners (multiplier block counted on rank 0 only);
-      // [3..6] are computed redundantly everywhere (atomics: rounding differs between ranks) - rank 0's copy is used;
-      // [7] is the time-limit flag of any rank.  One all-reduce distributes all of them.
-      if (rank != 0) HIPCHK(hipMemsetAsync(acc.p + 3, 0, 4 * sizeof(double), st));
+      // [3..6] are computed redundantly everywhere - rank 0's copy is used; [7] is the time-limit flag of any rank.
+      // Behind them travels rank 0's copy of the REPLICATED multiplier block nu[0..ng): every rank continues from the same
+      // bits, so the replicated state cannot drift apart between ranks whatever their libraries round like (identical by
+      // construction at every check iteration; x + 0 + ... + 0 is exact).  One all-reduce distributes all of it.
+      if (rank != 0) {
+        HIPCHK(hipMemsetAsync(acc.p + 3, 0, 4 * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(acc.p + 8, 0, (size_t)ng * sizeof(double), st));
+      } else HIPCHK(hipMemcpyAsync(acc.p + 8, nu.p, (size_t)ng * sizeof(double), hipMemcpyDeviceToDevice, st));
       const double tflag = (opt.max_time > 0 && loop_t0 > 0 && now_s() - loop_t0 > opt.max_time) ? 1.0 : 0.0;
       tflag_host = tflag;
       HIPCHK(hipMemcpyAsync(acc.p + 7, &tflag_host, sizeof(double), hipMemcpyHostToDevice, st));
-      allreduce(acc.p, 8);
+      allreduce(acc.p, 8 + (size_t)ng);
+      HIPCHK(hipMemcpyAsync(nu.p, acc.p + 8, (size_t)ng * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     HIPCHK(hipGetLastError());
   }
@@ -799,6 +836,8 @@ struct nnsdp_solver {
   }
   void check_finish() {
     HIPCHK(hipStreamSynchronize(st));
+    if (!big_idx.empty())     // rocSOLVER's convergence report of the library eigensolves since the last check
+      for (rocblas_int v : big_info.download()) big_fail = big_fail || v != 0;
     const double* a = acc_host;
     double z0n = 0;  // |z0| (scaled) is 1 when normalised; compute anyway
     for (double v : S.z0) z0n += v * v;
@@ -841,9 +880,9 @@ struct nnsdp_solver {
     if (opt.verbose)
       std::fprintf(stderr, "[nnsdp] it %6lld pres %.3e dres %.3e obj %.8g dobj %.8g sigma %.3g\n", iters_done, last_pres,
                    last_dres, last_pobj, last_dobj, sigma);
-    if (!(last_pres == last_pres) || !(last_dres == last_dres)) return NNSDP_STATUS_NUMERICAL_ERROR;
+    if (!(last_pres == last_pres) || !(last_dres == last_dres) || big_fail) return NNSDP_STATUS_NUMERICAL_ERROR;
     update_proj_tol();
-    if (trace_polish > 0 && iters_done >= next_trace) {
+    if (trace_polish > 0 && lead() && iters_done >= next_trace) {
       next_trace = iters_done + trace_polish;
       double tp = now_s();
       hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
@@ -868,19 +907,32 @@ struct nnsdp_solver {
     if (!advance_only && opt.cert_tol > 0 && P.nout && iters_done >= next_cert && std::max(last_pres, last_dres) <= std::min(1e-3, 0.1 * opt.cert_tol) &&
         std::fabs(last_pobj - last_dobj) <= opt.cert_tol * std::max(std::fabs(last_pobj), std::fabs(last_dobj))) {
       next_cert = std::max<long long>(iters_done + 100, iters_done * 11 / 10);
-      hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
-      HIPCHK(hipStreamSynchronize(st));
-      std::vector<double> gp = gs.download();
-      if (polish(gp)) {
-        double o = 0.0;
-        for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
-        o /= (S.zscale * S.cscale);
-        double ref = std::max(std::fabs(last_pobj), std::fabs(last_dobj));
-        if (opt.verbose) std::fprintf(stderr, "[nnsdp] it %6lld certified rho %.8g  admm %.8g  dual %.8g\n", iters_done, o, last_pobj, last_dobj);
-        if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) {
-          return NNSDP_STATUS_OPTIMAL;
+      // clique-sharded: every rank reaches this point at the same iteration (the conditions above are all-reduced numbers and
+      // replicated counters); rank 0 alone polishes and its verdict travels to everybody - ONE decision, so no rank can leave
+      // the loop while another enters the next iteration's all-reduce
+      std::vector<double> flag(2, 0.0);    // {stop, rank 0 failed}
+      std::string err;
+      if (lead()) {
+        try {
+          hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(S.ng, 256)), dim3(256), 0, st, S.ng, nu.p, d_sigma(), gs.p);
+          HIPCHK(hipStreamSynchronize(st));
+          std::vector<double> gp = gs.download();
+          if (polish(gp)) {
+            double o = 0.0;
+            for (int i = 0; i < S.ng; ++i) o += S.c[i] * gp[i];
+            o /= (S.zscale * S.cscale);
+            double ref = std::max(std::fabs(last_pobj), std::fabs(last_dobj));
+            if (opt.verbose) std::fprintf(stderr, "[nnsdp] it %6lld certified rho %.8g  admm %.8g  dual %.8g\n", iters_done, o, last_pobj, last_dobj);
+            if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) flag[0] = 1.0;
+          }
+        } catch (const std::exception& e) {
+          if (!sharded) throw;
+          err = e.what(); flag[1] = 1.0;
         }
       }
+      allreduce_host(flag);
+      if (flag[1] != 0.0) throw HipError(lead() ? err : std::string("rank 0 failed while polishing the certificate"));
+      if (flag[0] != 0.0) return NNSDP_STATUS_OPTIMAL;
     }
     if (!advance_only && opt.max_time > 0 && (sharded ? acc_host[7] > 0.0 : now_s() - t0 > opt.max_time)) return NNSDP_STATUS_TIME_LIMIT;
     // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
@@ -1059,7 +1111,10 @@ struct nnsdp_solver {
     return true;
   }
 
-  void finish(nnsdp_result* r, int status) {
+  // The certificate (gamma, eigmax) is computed ONCE: in clique-sharded mode by rank 0 alone, whose result travels to every
+  // rank through one all-reduce (the others contribute zeros) - identical on all ranks by construction, whatever the
+  // libraries behind the polish round like.  finish() is therefore a collective call in sharded mode.
+  void certificate(std::vector<double>& gam, double& lmax, bool& polished, DBuf<double>& Zd) {
     int ng = S.ng;
     hipLaunchKernelGGL(k_extract_gamma, dim3(cdiv(ng, 256)), dim3(256), 0, st, ng, nu.p, d_sigma(), gs.p);
     HIPCHK(hipStreamSynchronize(st));
@@ -1069,20 +1124,14 @@ struct nnsdp_solver {
       for (int i = 0; i < ng; ++i) o += S.c[i] * gsh[i];
       objective_admm = o / (S.zscale * S.cscale);
     }
-    bool polished = false;
+    polished = false;
     if (opt.polish) {
       std::vector<double> gp = gsh;
       polished = polish(gp);
       if (polished) gsh = gp;
     }
-    std::vector<double> gam(P.ng, 0.0);
+    gam.assign(P.ng, 0.0);
     for (int i = 0; i < ng; ++i) gam[S.keep[i]] = gsh[i] * S.ecol[i] / S.zscale;
-    // final Z and certificate in the reference's coordinates
-    if (!full) {
-      full.reset(new FullOperator());
-      nnsdp_problem pp = problem_view();
-      full->build(&pp);
-    }
     std::vector<int> elim;  // coordinates removed by the normalisation (full gamma index of their box multiplier): -> "large enough"
     if (opt.normalize && P.query_kind == NNSDP_QUERY_REACH) {
       for (int i = 0; i < P.nin; ++i)
@@ -1090,8 +1139,6 @@ struct nnsdp_solver {
       for (int t = 0; t < P.acdim; ++t)
         if (C.newpos[P.nin + t] < 0) elim.push_back(P.nin + P.nout + t);
     }
-    DBuf<double> Zd;
-    double lmax = 0;
     double gscale = 1.0;
     for (double v : gam) gscale = std::max(gscale, v);
     // multipliers of eliminated neurons are cost-free: raise them until eigmax(Z) stops improving
@@ -1110,6 +1157,36 @@ struct nnsdp_solver {
       for (int t : elim) gam[t] = best_big;
       full->assemble(gam, Zd, st);
       lmax = lambda_max_dense(roc->h, Zd, P.Zdim);
+    }
+  }
+
+  void finish(nnsdp_result* r, int status) {
+    // final Z and certificate in the reference's coordinates
+    if (!full) {
+      full.reset(new FullOperator());
+      nnsdp_problem pp = problem_view();
+      full->build(&pp);
+    }
+    std::vector<double> gam(P.ng, 0.0);
+    DBuf<double> Zd;
+    double lmax = 0;
+    bool polished = false;
+    if (!sharded) certificate(gam, lmax, polished, Zd);
+    else {
+      std::vector<double> pack(P.ng + 5, 0.0);     // gamma | eigmax | objective of the raw iterate | polish shift | polished | failed
+      std::string err;
+      if (rank == 0) {
+        try {
+          certificate(gam, lmax, polished, Zd);
+          std::copy(gam.begin(), gam.end(), pack.begin());
+          pack[P.ng] = lmax; pack[P.ng + 1] = objective_admm; pack[P.ng + 2] = polish_shift; pack[P.ng + 3] = polished ? 1.0 : 0.0;
+        } catch (const std::exception& e) { err = e.what(); std::fill(pack.begin(), pack.end(), 0.0); pack[P.ng + 4] = 1.0; }
+      }
+      allreduce_host(pack);
+      if (pack[P.ng + 4] != 0.0) throw HipError(rank == 0 ? err : std::string("rank 0 failed while computing the certificate"));
+      gam.assign(pack.begin(), pack.begin() + P.ng);
+      lmax = pack[P.ng]; objective_admm = pack[P.ng + 1]; polish_shift = pack[P.ng + 2]; polished = pack[P.ng + 3] != 0.0;
+      if (r->Z) full->assemble(gam, Zd, st);      // (fixed-order kernels: the same Z on every rank)
     }
     const double* gp = gam.data();
     if (r->gamma_in) std::memcpy(r->gamma_in, gp, P.nin * sizeof(double));
@@ -1482,6 +1559,17 @@ int nnsdp_solver_apply_minv(nnsdp_solver* s, const double* q, double* out, int32
   API_END
 }
 
+int nnsdp_solver_raw_multipliers(nnsdp_solver* s, double* out) {
+  API_BEGIN
+  if (!s || !out) throw std::invalid_argument("null argument");
+  HIPCHK(hipStreamSynchronize(s->st));
+  std::vector<double> h(s->S.ng);
+  if (s->S.ng) HIPCHK(hipMemcpy(h.data(), s->nu.p, (size_t)s->S.ng * sizeof(double), hipMemcpyDeviceToHost));
+  for (int g = 0; g < s->P.ng; ++g) out[g] = 0.0;
+  for (int g = 0; g < s->S.ng; ++g) out[s->S.keep[g]] = h[g];
+  API_END
+}
+
 int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r) {
   API_BEGIN
   if (!s || !r) throw std::invalid_argument("null argument");
@@ -1699,9 +1787,14 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
       int nb = 0;
       for (int b : big) nb = std::max(nb, cn[b]);
       DBuf<double> A, T, Dv, Ev; DBuf<rocblas_int> info;
-      A.alloc((size_t)nb * nb); T.alloc((size_t)nb * nb); Dv.alloc(nb); Ev.alloc(nb); info.alloc(1);
-      for (int b : big) project_big_block(rh.h, nullptr, cn[b], dnu.p + coff[b], dw.p + coff[b], A.p, T.p, Dv.p, Ev.p, info.p, dE.p + eoff[b]);
+      A.alloc((size_t)nb * nb); T.alloc((size_t)nb * nb); Dv.alloc(nb); Ev.alloc(nb); info.alloc(big.size()); info.zero();
+      for (size_t bi = 0; bi < big.size(); ++bi) {
+        const int b = big[bi];
+        project_big_block(rh.h, nullptr, cn[b], dnu.p + coff[b], dw.p + coff[b], A.p, T.p, Dv.p, Ev.p, info.p + bi, dE.p + eoff[b]);
+      }
       HIPCHK(hipDeviceSynchronize());
+      for (rocblas_int v : info.download())
+        if (v != 0) throw HipError("rocSOLVER dsyevd did not converge on a block above 128 (info = " + std::to_string((int)v) + ")");
     }
   }
   HIPCHK(hipEventRecord(e1, nullptr));

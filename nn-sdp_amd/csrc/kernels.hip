@@ -1664,13 +1664,14 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x_all_b(const IterArgs* __r
 }
 
 // nu <- nu + alpha (K x + q - w).  acc (may be null) accumulates at check iterations:
-//   acc[0] += |Kx+q-w|^2, acc[1] += |Kx+q|^2, acc[2] += |w|^2
+//   |Kx+q-w|^2, |Kx+q|^2, |w|^2 as per-workgroup partial sums acc[{0,1,2} * astride + block]; k_acc_reduce adds the partials
+//   in block order, so the residuals (and with them every stopping / penalty decision) are reproducible run to run
 __device__ __forceinline__ void update_nu_body(const int bid, int ng, long long nmat, const double* __restrict__ p,
                                                          const double* __restrict__ ww, const double* __restrict__ c,
                                                          const double* __restrict__ x, const unsigned int* __restrict__ gidx,
                                                          double* __restrict__ nu, const double* __restrict__ w,
                                                          double alpha, double* __restrict__ kappa, double* __restrict__ acc,
-                                                         long long lo, long long hi, int acc_s) {
+                                                         long long lo, long long hi, int acc_s, int astride) {
   // [lo, hi): the clique elements this rank owns (everything when not sharded); acc_s: count the
   // multiplier block in the residual sums (rank 0 only when sharded, the sums are all-reduced)
   __shared__ double red[8];
@@ -1696,8 +1697,10 @@ __device__ __forceinline__ void update_nu_body(const int bid, int ng, long long 
     r2 = block_sum(r2, red);
     k2 = block_sum(k2, red + 4);
     w2 = block_sum(w2, red);
-    if (threadIdx.x == 0) { atomicAdd(&acc[0], r2); atomicAdd(&acc[1], k2); atomicAdd(&acc[2], w2); }
+    if (threadIdx.x == 0) { acc[bid] = r2; acc[astride + bid] = k2; acc[2 * astride + bid] = w2; }
   }
+  // the one-shot penalty rescale is consumed: kappa is READ only by the projection and the A' kernels, which precede this
+  // launch on the iteration's single stream, and never by this kernel - so resetting it here cannot race with a reader
   if (i == 0 && kappa) *kappa = 1.0;
 }
 __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, const double* __restrict__ p,
@@ -1705,11 +1708,11 @@ __global__ __launch_bounds__(kThreads) void k_update_nu(int ng, long long nmat, 
                                                          const double* __restrict__ x, const unsigned int* __restrict__ gidx,
                                                          double* __restrict__ nu, const double* __restrict__ w,
                                                          double alpha, double* __restrict__ kappa, double* __restrict__ acc,
-                                                         long long lo, long long hi, int acc_s) { update_nu_body(blockIdx.x, ng, nmat, p, ww, c, x, gidx, nu, w, alpha, kappa, acc, lo, hi, acc_s); }
+                                                         long long lo, long long hi, int acc_s, int astride) { update_nu_body(blockIdx.x, ng, nmat, p, ww, c, x, gidx, nu, w, alpha, kappa, acc, lo, hi, acc_s, astride); }
 __global__ __launch_bounds__(kThreads) void k_update_nu_b(const IterArgs* __restrict__ A) {
   const IterArgs a = A[blockIdx.y];
   if ((long long)blockIdx.x * kThreads >= (long long)a.ng + a.nmat) return;
-  update_nu_body(blockIdx.x, a.ng, a.nmat, a.p, a.ww, a.c, a.x, a.gidx, a.nu, a.w, a.alpha, a.kappa, nullptr, 0LL, a.nmat, 1);
+  update_nu_body(blockIdx.x, a.ng, a.nmat, a.p, a.ww, a.c, a.x, a.gidx, a.nu, a.w, a.alpha, a.kappa, nullptr, 0LL, a.nmat, 1, 0);
 }
 
 // check iteration, dual side: t[e] = (K'y)[e] = sum_g A[e,g] ys[g] + wgt * sum_src y_k[src],
@@ -1720,7 +1723,7 @@ __global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, int nre
                                                           const long long* __restrict__ soff, const unsigned char* __restrict__ isdiag,
                                                           const double* __restrict__ nu, const double* __restrict__ w,
                                                           const double* __restrict__ z0, const double* __restrict__ sigma,
-                                                          double* __restrict__ acc, const double* __restrict__ hsum) {
+                                                          double* __restrict__ acc, const double* __restrict__ hsum, int astride) {
   // hsum != null (clique-sharded mode): the clique part of K'y/sigma, already summed over ranks.
   // Blocks [0, nreg): 16 lanes per entry, rows with more than kLongRow nonzeros skipped; blocks [nreg, nreg + nlong): one
   // workgroup per long row (the (a,a) entry meets every multiplier: 3 203 nonzeros at W40-D20, 200 steps for 16 lanes)
@@ -1746,8 +1749,7 @@ __global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, int nre
     if (mine && sub == 0) { double t = sg * s; double d = t - z0[e]; d2 = d * d; t2 = t * t; }
   } else {
     const int b = blockIdx.x - nreg;
-    if (b >= nlong) return;
-    const int e = longrows[b];
+    const int e = longrows[b];      // (the grid is exactly nreg + nlong workgroups)
     double s = 0.0, h = 0.0;
     for (int q = ptr[e] + threadIdx.x; q < ptr[e + 1]; q += kThreads) { double v = nu[col[q]]; s += val[q] * (v < 0.0 ? v : 0.0); }
     if (hsum) { if (threadIdx.x == 0) h = hsum[e]; }
@@ -1761,13 +1763,13 @@ __global__ __launch_bounds__(kThreads) void k_check_dual(int NE, int ng, int nre
   }
   d2 = block_sum(d2, red);
   t2 = block_sum(t2, red + 4);
-  if (threadIdx.x == 0) { atomicAdd(&acc[3], d2); atomicAdd(&acc[4], t2); }
+  if (threadIdx.x == 0) { acc[3 * astride + blockIdx.x] = d2; acc[4 * astride + blockIdx.x] = t2; }
 }
 
 // acc[5] += -c' ys  (scaled primal objective), acc[6] += z0' x (scaled dual objective)
 __global__ __launch_bounds__(kThreads) void k_check_obj(int ng, int NE, const double* __restrict__ nu, const double* __restrict__ c,
                                                          const double* __restrict__ z0, const double* __restrict__ x,
-                                                         const double* __restrict__ sigma, double* __restrict__ acc) {
+                                                         const double* __restrict__ sigma, double* __restrict__ acc, int astride) {
   __shared__ double red[8];
   int i = blockIdx.x * kThreads + threadIdx.x;
   double a = 0.0, b = 0.0;
@@ -1775,8 +1777,24 @@ __global__ __launch_bounds__(kThreads) void k_check_obj(int ng, int NE, const do
   if (i < NE) b = z0[i] * x[i];
   a = block_sum(a, red);
   b = block_sum(b, red + 4);
-  if (threadIdx.x == 0) { atomicAdd(&acc[5], a); atomicAdd(&acc[6], b); }
+  if (threadIdx.x == 0) { acc[5 * astride + blockIdx.x] = a; acc[6 * astride + blockIdx.x] = b; }
 }
+
+// second stage of the residual sums: acc[q] = sum of the nb[q] workgroup partials of quantity q, added in a fixed order
+// (thread t takes partials t, t + 256, ...; then the block tree) - no atomics anywhere on the way to a stopping decision.
+__global__ __launch_bounds__(kThreads) void k_acc_reduce(const double* __restrict__ accp, int astride, int nb_upd, int nb_dual, int nb_obj,
+                                                          double* __restrict__ acc) {
+  __shared__ double red[8];
+#pragma unroll 1
+  for (int q = 0; q < 7; ++q) {
+    const int nb = q < 3 ? nb_upd : (q < 5 ? nb_dual : nb_obj);
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kThreads) s += accp[(size_t)q * astride + b];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) acc[q] = s;
+  }
+}
+
 
 // gs[g] = max(-ys[g], 0), ys = sigma * min(nu_s, 0)
 __global__ void k_extract_gamma(int ng, const double* __restrict__ nu, const double* __restrict__ sigma, double* __restrict__ gs) {

@@ -107,8 +107,9 @@ struct ProblemCopy {
     // `@assert smin <= smax` (activ_sector.jl:13) compares two Julia vectors, i.e. lexicographically: the first entry that
     // differs decides.  (The tanh branch of makeSectorMinMax returns smin > smax on negative intervals, :76-77; the sector
     // generator is symmetric in the two slopes, so that is harmless, and it passes the reference's assertion.)
-    for (int i = 0; i < acdim; ++i) {
+    for (int i = 0; i < acdim; ++i)     // every entry: the lexicographic loop below stops at the first differing one
       if (smin[i] != smin[i] || smax[i] != smax[i]) throw std::invalid_argument("smin / smax contain NaN");
+    for (int i = 0; i < acdim; ++i) {
       if (smin[i] == smax[i]) continue;
       if (smin[i] > smax[i]) throw std::invalid_argument("smin <= smax violated (activ_sector.jl:13)");
       break;

@@ -172,7 +172,10 @@ class QcActivSector:
         self.smin, self.smax = _f64(self.smin), _f64(self.smax)
         assert self.acxdim == len(self.smin) == len(self.smax)
         assert 0 <= self.beta
-        # `@assert smin <= smax` (activ_sector.jl:13) is Julia's lexicographic vector comparison
+        # `@assert smin <= smax` (activ_sector.jl:13) is Julia's lexicographic vector comparison; a NaN anywhere (the reference's
+        # tanh branch produces 0/0 for a pre-activation bound that is exactly 0, activ_sector.jl:74-86) is rejected outright:
+        # the lexicographic test stops at the first differing entry and would let it through into the operator
+        assert not (np.isnan(self.smin).any() or np.isnan(self.smax).any()), "smin / smax contain NaN"
         assert self.smin.tolist() <= self.smax.tolist()
 
     @property
@@ -447,6 +450,12 @@ class Solver:
         _lib.check(self.lib.nnsdp_solver_apply_minv(self.h, q.ctypes.data_as(_lib.c_double_p), out.ctypes.data_as(_lib.c_double_p),
                                                     C.byref(st), C.byref(nb)))
         return out, bool(st.value), int(nb.value)
+
+    def raw_multipliers(self) -> np.ndarray:
+        """the multiplier block of the solver's fixed-point variable (solver coordinates; diagnostic / test entry)"""
+        out = np.zeros(self.cp.ngamma)
+        _lib.check(self.lib.nnsdp_solver_raw_multipliers(self.h, out.ctypes.data_as(_lib.c_double_p)))
+        return out
 
     def residuals(self):
         a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()

@@ -31,7 +31,14 @@ def main():
     s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()))
     s.set_comm_callback(world, rank, allreduce)
     s.iterate(300)
+    # diagnostics of the REPLICATED state: the Woodbury core applied to a fixed vector and the multiplier block after
+    # 300 plain iterations (no check iteration yet, so no resynchronisation has happened), as hex digests the parent compares
+    import hashlib
+    qfix = np.cos(np.arange(s.cp.ngamma) * 0.37)
+    res["minv_digest"] = hashlib.sha256(s.apply_minv(qfix)[0].tobytes()).hexdigest()
+    res["mult300_digest"] = hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest()
     res["after_300"] = list(s.residuals())
+    res["mult301_digest"] = hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest()    # after a check iteration: resynchronised
     s.close()
     # (b) a whole solve: every stopping / penalty / tolerance decision is collective
     s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
@@ -43,6 +50,14 @@ def main():
                         gamma=np.concatenate([sol.values[k] for k in ("γin", "γout", "γac1", "γac2")]).tolist())
     s.close()
     res["allreduce_calls"] = calls[0]
+    # (c) the certified-gap stopping rule (cert_tol) in sharded mode: rank 0 polishes, the stop flag is all-reduced
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-7, cert_tol=1e-3, max_iters=200000, max_time=200))
+    s.set_comm_callback(world, rank, allreduce)
+    sol = s.run()
+    res["cert"] = dict(status=sol.termination_status, iters=int(sol.summary["iters"]), rho=float(sol.objective_value),
+                       pres=float(sol.summary["pres"]), dres=float(sol.summary["dres"]), lambda_max=float(sol.summary["lambda_max"]),
+                       gamma=np.concatenate([sol.values[k] for k in ("γin", "γout", "γac1", "γac2")]).tolist())
+    s.close()
     bn, st = na.shardPlan(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp()), world)
     res["blocks_owned"] = [int(st[rank]), int(st[rank + 1])]
     dist.barrier()

@@ -337,9 +337,19 @@ def test_certified_gap_stopping_rule(name, beta, mode):
     assert fast.termination_status == "OPTIMAL"
     assert fast.summary["lambda_max"] <= 1e-6 and min(np.min(fast.values[k]) for k in ("γin", "γout", "γac1", "γac2")) >= 0.0
     assert fast.objective_value >= opt * (1 - 1e-4)
-    # measured 4.9e-4 .. 9.4e-4 on these cases; the rule compares with ADMM ESTIMATES of the optimum (trusted at residuals <= cert_tol / 10),
-    # and the residual sums are accumulated with atomics, so the stopping iteration can move by a check: 20 % slack on the 1e-3
-    assert fast.objective_value - opt <= 1.2e-3 * opt, (fast.objective_value, opt, fast.summary["iters"])
+    # SURVEY section 8d's epsilon; the residual sums are added in a fixed order (k_acc_reduce), so the stopping iteration is reproducible
+    assert fast.objective_value - opt <= 1e-3 * opt, (fast.objective_value, opt, fast.summary["iters"])
+
+
+def test_solve_is_reproducible_run_to_run():
+    """no atomics on the way to a stopping / penalty decision: two runs of one solve stop at the same iteration with the same bits"""
+    q = helpers.product_query(helpers.load_problem("W40-D20", 0))
+    o = na.AdmmSdpOptions(max_iters=400000, decomp_mode=na.DoubleDecomp(), cert_tol=1e-3, max_time=100)
+    a, b = na.runQuery(q, o), na.runQuery(q, o)
+    assert a.summary["iters"] == b.summary["iters"] and a.termination_status == b.termination_status
+    for k in ("γin", "γout", "γac1", "γac2"):
+        assert np.array_equal(a.values[k], b.values[k]), k
+    assert a.summary["pres"] == b.summary["pres"] and a.summary["dres"] == b.summary["dres"]
 
 
 def test_full_size_solver_invariants_w40_d20():

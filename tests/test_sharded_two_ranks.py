@@ -35,10 +35,24 @@ def test_two_rank_sharded_solve_matches_the_serial_solve(name, beta, tmp_path):
     s.iterate(300)
     ref300 = s.residuals()
     s.close()
-    ref = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    try:
+        ref = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
+        refc = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-7, cert_tol=1e-3, max_iters=200000, max_time=200))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:            # a failure above must not leave rank processes behind on the card
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     r0, r1 = (json.load(open(o)) for o in outs)
+    # diagnostics of the replicated state, kept beside the run (gpurun_out/ travels back from the GPU box)
+    diag = {k: [r0[k], r1[k]] for k in ("minv_digest", "mult300_digest", "mult301_digest")}
+    os.makedirs(os.path.join(helpers.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(helpers.ROOT, "gpurun_out", f"shard_diag_{name}.json"), "w") as fh:
+        json.dump(diag, fh, indent=1)
+    print("replicated-state digests equal on both ranks:", {k: v[0] == v[1] for k, v in diag.items()})
+    assert diag["mult301_digest"][0] == diag["mult301_digest"][1]   # after a check iteration the multiplier block IS rank 0's, bit for bit
     # (a) 300 plain iterations: the same iterate as the serial run (the consensus sum is associated differently: 1e-9)
     for r in (r0, r1):
         assert np.allclose(r["after_300"], ref300, rtol=1e-8, atol=1e-12), (r["after_300"], ref300)
@@ -53,3 +67,11 @@ def test_two_rank_sharded_solve_matches_the_serial_solve(name, beta, tmp_path):
     assert a["lambda_max"] <= 1e-6 and min(a["gamma"]) >= 0.0
     assert r0["blocks_owned"][1] == r1["blocks_owned"][0] and r0["blocks_owned"][0] == 0
     assert r0["allreduce_calls"] == r1["allreduce_calls"] >= a["iters"]
+    # (c) the certified-gap rule under sharding: one decision (rank 0 polishes, the flag is all-reduced), one certificate
+    ca, cb = r0["cert"], r1["cert"]
+    assert ca["status"] == cb["status"] == refc.termination_status == "OPTIMAL"
+    assert ca["iters"] == cb["iters"] and ca["iters"] < a["iters"] + 10**9
+    assert np.array_equal(np.array(ca["gamma"]), np.array(cb["gamma"]))
+    assert max(ca["pres"], ca["dres"]) > 1e-7                       # it was the certified-gap rule that stopped the solve
+    assert abs(ca["rho"] - refc.objective_value) <= 1e-3 * abs(refc.objective_value)
+    assert ca["lambda_max"] <= 1e-6 and min(ca["gamma"]) >= 0.0
