@@ -31,6 +31,7 @@ struct PathDecomp <: DecompMode end
   device::Int = -1
   interval_guard::Float64 = 5e-5
   minv_mode::Int = 0
+  proj_refine::Bool = true
 end
 
 # field order and types must match include/nnsdp.h
@@ -45,7 +46,7 @@ end
 struct COptions
   decomp_mode::Int32; max_iters::Int32; eps_rel::Float64; max_time::Float64; sigma::Float64; alpha::Float64
   adapt_every::Int32; check_every::Int32; normalize::Int32; warm_start::Int32; proj_tol::Float64
-  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32; interval_guard::Float64; minv_mode::Int32
+  polish::Int32; cert_tol::Float64; verbose::Int32; device::Int32; interval_guard::Float64; minv_mode::Int32; proj_refine::Int32
 end
 mutable struct CResult
   gamma_in::Ptr{Float64}; gamma_out::Ptr{Float64}; gamma_ac1::Ptr{Float64}; gamma_ac2::Ptr{Float64}; Z::Ptr{Float64}
@@ -53,6 +54,7 @@ mutable struct CResult
   t_setup::Float64; t_solve::Float64; t_total::Float64; t_eig::Float64
   n_cliques::Int32; max_clique::Int32; eig_flops_per_iter::Int64; eig_bytes_per_iter::Int64; avg_sweeps::Float64
   objective_admm::Float64; polish_shift::Float64
+  refine_blocks::NTuple{4,Int64}
 end
 
 function runQuery(query::Query, opts::AdmmSdpOptions)
@@ -88,9 +90,9 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
     f1 > f0 || error("obj_func must be increasing in γout[1]")
   end
   copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
-                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device, opts.interval_guard, opts.minv_mode)
+                   opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device, opts.interval_guard, opts.minv_mode, opts.proj_refine)
   res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
-                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0)
+                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0, (0, 0, 0, 0))
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin
     p(v) = isempty(v) ? Ptr{Float64}(C_NULL) : pointer(v)
     prob = CProblem(ffnet.K, pointer(xdims), pointer(M), pointer(x1min), pointer(x1max), pointer(acymin), pointer(acymax),

@@ -298,7 +298,8 @@ struct nnsdp_solver {
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
-  DBuf<int> d_cn, d_sptr, d_stats, d_long;
+  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate;
+  double refine_acc = 30.0, refine_kcap = 0.05;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -445,7 +446,11 @@ struct nnsdp_solver {
     }
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
-    d_stats.alloc(4); d_stats.zero();
+    d_stats.alloc(8); d_stats.zero();
+    d_rstate.alloc(std::max(ncl, 1)); d_rstate.zero();
+    if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
+    if (const char* e = std::getenv("NNSDP_REFINE_ACC")) refine_acc = std::atof(e);
+    if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) refine_kcap = std::atof(e);
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -692,12 +697,13 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
+    a.refine = opt.proj_refine; a.rstate = d_rstate.p + k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
     }
     if (!small_idx.empty()) {
-      a.cn = d_cn_s.p; a.coff = d_coff_s.p;
+      a.cn = d_cn_s.p; a.coff = d_coff_s.p; a.rstate = d_rstate.p;      // (compacted block list: the first small_idx.size() slots)
       nnsdp::launch_proj(a, (int)small_idx.size(), nmax_small, v_lds, lds_bytes, st, proj_alg);
     }
     for (size_t bi = 0; bi < big_idx.size(); ++bi) {
@@ -1215,6 +1221,7 @@ struct nnsdp_solver {
     r->eig_bytes_per_iter = b;
     {
       std::vector<int> stv = d_stats.download();
+      for (int i = 0; i < 4; ++i) r->refine_blocks[i] = stv[4 + i];
       r->objective_admm = objective_admm;
     r->polish_shift = polished ? polish_shift : -1.0;
     r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
@@ -1331,6 +1338,7 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
+      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap;
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));
@@ -1467,6 +1475,7 @@ void nnsdp_default_options(nnsdp_options* o) {
   o->device = -1;
   o->interval_guard = 5e-5;
   o->minv_mode = 0;
+  o->proj_refine = 1;
 }
 
 int nnsdp_problem_dims(const nnsdp_problem* p, int32_t* Zdim, int32_t* acdim, int32_t* nac2, int32_t* ngamma) {
@@ -1767,6 +1776,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
+  a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
@@ -1806,6 +1816,60 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   if (kernel_ms) *kernel_ms = ms;
   HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
   if (eigvals) HIPCHK(hipMemcpy(eigvals, dE.p, etot * sizeof(double), hipMemcpyDeviceToHost));
+  API_END
+}
+
+int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
+                           int32_t* outcome, double* kernel_ms) {
+  API_BEGIN
+  if (batch < 0) throw std::invalid_argument("batch must be >= 0");
+  if (batch == 0) return 0;
+  if (!n || !mats || !basis || !out) throw std::invalid_argument("null argument");
+  if (!(tol > 0.0)) throw std::invalid_argument("tol must be > 0");
+  require_gpu();
+  std::vector<int> cn(n, n + batch);
+  std::vector<long long> coff(batch + 1);
+  long long tot = 0;
+  int nmax = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (cn[b] < 1 || cn[b] > 128) throw std::invalid_argument("matrix dimension must be in 1..128 (the LDS-resident kernel)");
+    coff[b] = tot;
+    tot += (long long)cn[b] * cn[b];
+    nmax = std::max(nmax, cn[b]);
+  }
+  coff[batch] = tot;
+  DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV;
+  dcn.upload(cn); dco.upload(coff);
+  dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot);
+  dst.alloc(8); dst.zero(); drs.alloc(batch); drs.zero();
+  HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
+  const int alg = proj_algorithm(nmax);
+  bool v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
+  size_t lds = proj_lds_bytes(nmax, v_lds, alg);
+  if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
+  ProjArgs a;
+  a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr;
+  a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
+  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05;
+  if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);
+  if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) a.refine_kcap = std::atof(e);
+  struct Events {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  } ev;
+  HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
+  HIPCHK(hipEventRecord(ev.e0, nullptr));
+  launch_proj(a, batch, nmax, v_lds, lds, nullptr, alg);
+  HIPCHK(hipEventRecord(ev.e1, nullptr));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  if (kernel_ms) *kernel_ms = ms;
+  HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(basis, dV.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+  if (outcome) { std::vector<int> st = dst.download(); for (int i = 0; i < 4; ++i) outcome[i] = st[4 + i]; }
   API_END
 }
 

@@ -61,8 +61,13 @@ struct ProjArgs {
   double* eig;            // packed eigenvalues (out, may be null)
   const double* kappa;    // device scalar: nu <- w + kappa (nu - w) (penalty change), may be null
   const double* tol_dev;  // device scalar overriding tol (lets the host adapt it between graph launches), may be null
-  int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen
+  int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen, [2..3] rotation counts, [4..7] refinement stage: blocks
+                          // accepted without a step / after one step / sent on to the sweeps / not attempted (back-off)
   int warm;               // 1: use Vg as the starting basis
+  int refine;             // 1: warm blocks first try the GEMM-only refinement of the persistent basis (ping-pong variant only)
+  int* rstate;            // refinement back-off per block: (level << 8) | iterations still to skip (may be null)
+  double refine_acc;      // a refinement step is accepted without a check when its PREDICTED off(A) is below refine_acc x tol |A|
+  double refine_kcap;     // pairs whose first-order rotation angle B_ij / (d_j - d_i) exceeds this are left to the sweeps
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
 };
@@ -299,7 +304,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   sec_t[1] = clock64();
 #endif
   const int nv = V_LDS ? np : n;  // rows/cols of V that exist
-  if (warm && V_LDS) {
+  // A <- V' A V on the matrix cores (V in LDS); a lambda because the refinement stage's fall-back re-runs it
+  auto congruence = [&]() {
     // A <- V' A V with v_mfma_f64_16x16x4_f64: T = A V (all 16x16 tiles), then A' = V' T (lower tiles; the
     // Jacobi sweeps read the lower triangle only).  Operand maps (verified on gfx950): lane l holds
     // A[l&15][l>>4], B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
@@ -365,6 +371,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         for (int i = (tid & 63) + j + 1; i < npg; i += 64) A[j * lda + i] = A[i * lda + j];
       __syncthreads();
     }
+  };
+  if (warm && V_LDS) {
+    congruence();
   } else if (warm) {
     // (blocks too large to keep V in LDS) A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
     //   T = A V   (written over A),   A' = V' T   (written over T)
@@ -495,6 +504,275 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 #endif
   int sweeps = 0;
   int pofs = 0;   // systolic sweeps: eigen-index j of the result sits at position j + pofs (the padded index travels)
+  // ---- refinement stage (ping-pong variant, warm blocks): GEMM-only update of the PERSISTENT eigenbasis.
+  // Once the ADMM iterate moves slowly, B = V'AV is diagonal up to a perturbation E far below the spectral gaps, and ONE simultaneous
+  // first-order rotation of all pairs, K_ij = B_ij / (d_j - d_i), does what a Jacobi sweep does (quadratic: off(B) -> ~ |E| |K|) at
+  // the price of two more products on the matrix cores instead of np rounds of plane rotations.  The step is Ogita & Aishima's
+  // refinement (Japan J. Indust. Appl. Math. 35, 2018): E~_ij = (B_ij + l_j R_ij) / (l_j - l_i), E~_ii = R_ii / 2 with
+  // R = I - V'V, V <- V (I + E~), which restores orthogonality to second order at the same time.  Pairs it cannot resolve
+  // (|B_ij| > kcap |d_j - d_i|: near-degenerate pairs) get E~_ij = R_ij / 2 and their coupling counts as unresolved; it is far
+  // below the tolerance late in a solve (both eigenvalues sit in the near-zero cluster) and large early, when the block goes on to
+  // the exact sweeps below.  Acceptance without a check of the result: predicted off = 1.5 |E|_F |K|_F + unresolved <=
+  // refine_acc x tol |A|_F (measured on oracle iterates: tests/experiments/refine_proj2.py).
+  bool refined = false;
+  int side_force = 0;     // refinement step accepted for ONE side of the spectrum: the reconstruction must use it (+1 positive, -1 negative)
+  if constexpr (PP) {
+    int wait = 0, level = 0;
+    if (a.rstate) { const int rs = a.rstate[k]; wait = rs & 255; level = rs >> 8; }
+    if (warm && a.refine != 0 && wait == 0) {
+      constexpr int NW = NT / 64;
+      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lc = lane >> 4;
+      const int nt = npg >> 4, ntl = nt * (nt + 1) / 2, ks = (np + 3) >> 2;
+      double* const dvec = desc;            // B_ii
+      double* const rdg = desc + npg;       // R_ii
+      double* const cs1 = desc + 2 * npg;   // column sums of E~^2
+      double* const cs2 = desc + 3 * npg;   // column sums of E~^2 d
+      int tti[2], ttj[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int t = wv + m * NW;
+        int ti = -1, tj = -1;
+        if (t < ntl) { ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ++ti; tj = t - ti * (ti + 1) / 2; }
+        tti[m] = ti; ttj[m] = tj;
+      }
+      d4_t g[2];
+      // Gram matrix V'V on the wave's lower tiles (registers)
+      auto gram = [&]() {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+          if (tti[m] >= 0) {
+            const double* ap = V + lc + (size_t)(16 * tti[m] + lr) * ldv;
+            const double* bp = V + lc + (size_t)(16 * ttj[m] + lr) * ldv;
+            for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk], c, 0, 0, 0);
+          }
+          g[m] = c;
+        }
+      };
+      // R_ii and the squared norm of R from the tiles
+      auto gram_diag = [&]() {
+        double r2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if (tti[m] >= 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+              if (i < n && j < n) {
+                if (i == j) { const double v = 1.0 - g[m][r]; rdg[i] = v; r2 += v * v; }
+                else if (i > j) r2 += 2.0 * g[m][r] * g[m][r];
+              } else if (i == j && i < npg) rdg[i] = 0.0;
+            }
+        return block_sum(r2, red);
+      };
+      // V <- V + V X with X in the A buffer (all tiles; accumulators in registers, V updated in place)
+      auto v_update = [&]() {
+        constexpr int MAXT = 3;
+        d4_t acc[MAXT];
+#pragma unroll
+        for (int m = 0; m < MAXT; ++m) {
+          const int t = wv + m * NW;
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+          if (t < nt * nt) {
+            const int ti = t / nt, tj = t - ti * nt;
+            const double* ap = V + 16 * ti + lr + (size_t)lc * ldv;       // V(i, k)
+            const double* bp = A + lc * lda + 16 * tj + lr;               // X(k, j)
+            for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(size_t)4 * kk * ldv], bp[4 * kk * lda], c, 0, 0, 0);
+          }
+          acc[m] = c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MAXT; ++m) {
+          const int t = wv + m * NW;
+          if (t < nt * nt) {
+            const int ti = t / nt, tj = t - ti * nt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) V[16 * ti + lc + 4 * r + (size_t)(16 * tj + lr) * ldv] += acc[m][r];
+          }
+        }
+        __syncthreads();
+      };
+      gram();
+      if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
+      double r2 = uniform(gram_diag());           // (two barriers inside: dvec / rdg are visible afterwards)
+      // analysis of the wave's pairs (i > j): nothing is written yet, so a rejected block reaches the sweeps untouched
+      const double kcap = a.refine_kcap;
+      // An unresolved coupling between two eigenvalues of the SAME sign costs nothing when the projection is rebuilt from the OTHER
+      // side of the spectrum (W = sum over the positive side, or sym(nu) minus the sum over the negative side): the untouched side
+      // only has to keep its inertia (b^2 < d_i d_j).  So the unresolved mass is kept per side and the side to rebuild from is the
+      // smaller one when that passes, the other one when only that passes (measured on W40-D20 iterates at residual 4e-5: rejected
+      // blocks 25 % -> 7 %; the near-degenerate pairs sit almost always among the negative eigenvalues).
+      double off2 = 0.0, k2 = 0.0, unpp = 0.0, unnn = 0.0, unx = 0.0, kd2 = 0.0;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (tti[m] >= 0)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+            if (i > j && i < n) {
+              const double b = A[i * lda + j], rr = -g[m][r];
+              const double li = dvec[i] * (1.0 + rdg[i]), lj = dvec[j] * (1.0 + rdg[j]);
+              const double gap = lj - li;
+              off2 += 2.0 * b * b;
+              if (fabs(b) <= kcap * fabs(gap) && gap != 0.0) {
+                const double e = (b + lj * rr) * rcp_nr2(gap), f = rr - e;
+                k2 += e * e + f * f;
+                kd2 += e * e * lj * lj + f * f * li * li;
+              } else {
+                k2 += 0.5 * rr * rr;
+                const double dd = dvec[i] * dvec[j];
+                if (b * b < dd) { if (dvec[i] > 0.0) unpp += 2.0 * b * b; else unnn += 2.0 * b * b; }   // same sign, inertia kept
+                else unx += 2.0 * b * b;
+              }
+            }
+          }
+      off2 = uniform(block_sum(off2, red));
+      k2 = uniform(block_sum(k2, red));
+      unpp = uniform(block_sum(unpp, red));
+      unnn = uniform(block_sum(unnn, red));
+      unx = uniform(block_sum(unx, red));
+      kd2 = uniform(block_sum(kd2, red));
+      const double cpos = uniform(block_sum((tid < n && dvec[tid] > 0.0) ? 1.0 : 0.0, red));
+      const double cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
+      const double T = tolv * sqrt(fro2);
+      // predicted error of the projection after one step: second-order residual coupling |[E, K]| / 2 <= |E| |K| (measured: 0.3 |E| |K|
+      // at the median, 1.3 at the worst), the couplings left alone, and the third-order defect of exp(K) ~ I + K + K^2 / 2, which hits
+      // the projection as |K^3 D| / 3 <= |K|^2 |K D| / 3 (D = eigenvalues: large rotations between eigenvalues near zero cost nothing)
+      const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
+      const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);    // rebuilding from the positive / negative side
+      const bool prefer_pos = cpos <= cneg;
+      int outcome;      // 0: converged as it is, 1: one step, 2: on to the sweeps
+      if (off2 <= T * T && r2 <= tolv * tolv) outcome = 0;
+      else if (r2 > 1e-4) outcome = 2;
+      else if ((prefer_pos ? pred_pos : pred_neg) <= a.refine_acc * T) { outcome = 1; side_force = prefer_pos ? 1 : -1; }
+      else if ((prefer_pos ? pred_neg : pred_pos) <= a.refine_acc * T) { outcome = 1; side_force = prefer_pos ? -1 : 1; }
+      else outcome = 2;
+      if (outcome == 1) {
+        // E~ over B (both triangles and the diagonal), column sums for the second-order eigenvalues, V <- V (I + E~)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if (tti[m] >= 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+              if (i > j) {
+                double e = 0.0, f = 0.0;
+                if (i < n) {
+                  const double b = A[i * lda + j], rr = -g[m][r];
+                  const double li = dvec[i] * (1.0 + rdg[i]), lj = dvec[j] * (1.0 + rdg[j]);
+                  const double gap = lj - li;
+                  if (fabs(b) <= kcap * fabs(gap) && gap != 0.0) { e = (b + lj * rr) * rcp_nr2(gap); f = rr - e; }
+                  else { e = 0.5 * rr; f = e; }
+                }
+                A[i * lda + j] = e; A[j * lda + i] = f;
+              } else if (i == j) A[i * lda + i] = 0.5 * rdg[i];
+            }
+        __syncthreads();
+        {
+          const int col = tid >> 3, part = tid & 7;     // 8 lanes per column
+          double s1 = 0.0, s2 = 0.0;
+          if (col < n)
+            for (int kx = part; kx < n; kx += 8)
+              if (kx != col) { const double e = A[kx * lda + col]; s1 += e * e; s2 += e * e * dvec[kx]; }
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 8); s2 += __shfl_xor(s2, o, 8); }
+          if (part == 0 && col < npg) { cs1[col] = s1; cs2[col] = s2; }
+        }
+        // second-order term of the rotation: X = E~ + E~^2 / 2 ~ exp(K) - I, so that V (I + X) is orthogonal to THIRD order - with
+        // the first-order step alone the projection carries an error |K^2 D| that no later iteration takes back.  E~^2 is symmetric
+        // (E~ is antisymmetric up to R): lower tiles on the matrix cores, added to both triangles
+        {
+          d4_t sq[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            d4_t c = {0.0, 0.0, 0.0, 0.0};
+            if (tti[m] >= 0) {
+              const double* ap = A + (16 * tti[m] + lr) * lda + lc;      // E~(i, k)
+              const double* bp = A + lc * lda + 16 * ttj[m] + lr;        // E~(k, j)
+              for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk * lda], c, 0, 0, 0);
+            }
+            sq[m] = c;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            if (tti[m] >= 0)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+                if (i < n && j < n) {
+                  if (i > j) { A[i * lda + j] += 0.5 * sq[m][r]; A[j * lda + i] += 0.5 * sq[m][r]; }
+                  else if (i == j) A[i * lda + i] += 0.5 * sq[m][r];
+                }
+              }
+          __syncthreads();
+        }
+        v_update();
+        {
+          const int col = tid >> 3, part = tid & 7;
+          double nr = 0.0;
+          if (col < n)
+            for (int rx = part; rx < n; rx += 8) { const double v = V[rx + (size_t)col * ldv]; nr += v * v; }
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) nr += __shfl_xor(nr, o, 8);
+          __syncthreads();      // every E~ entry has been read (the products above)
+          if (part == 0 && col < npg) {
+            double lamn = 0.0;
+            if (col < n) { const double d = dvec[col]; lamn = (d * (1.0 + rdg[col] + cs1[col]) - cs2[col]) / nr; }
+            A[col * lda + col] = lamn;
+          }
+        }
+        __syncthreads();
+        refined = true;
+      } else if (outcome == 0) {
+        refined = true;
+      } else if (r2 > a.refine_acc * a.refine_acc * tolv * tolv) {
+        // (a defect below the error level accepted for refinement steps goes to the sweeps as it is: they diagonalise B exactly,
+        // the projection then carries that defect once, and the next refinement step's R term removes it)
+        // on to the sweeps, which keep V only as orthogonal as they find it: after refinement steps V is orthogonal to second order
+        // in E~, so it is first put right by Newton-Schulz steps V <- V (I + R / 2) (R -> 3/8 R^2 each), then B is rebuilt
+        for (int pass = 0; pass < 3 && r2 > 1e-24; ++pass) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            if (tti[m] >= 0)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+                if (i > j) { const double e = (i < n) ? -0.5 * g[m][r] : 0.0; A[i * lda + j] = e; A[j * lda + i] = e; }
+                else if (i == j) A[i * lda + i] = 0.5 * rdg[i];
+              }
+          __syncthreads();
+          v_update();
+          gram();
+          r2 = uniform(gram_diag());
+        }
+        for (int j = wv; j < npg; j += NW)
+          for (int i = lane; i < npg; i += 64) {
+            double v = 0.0;
+            if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
+            A[i * lda + j] = v;
+          }
+        __syncthreads();
+        congruence();
+      }
+      if (tid == 0) {
+        if (a.stats) atomicAdd(&a.stats[4 + outcome], 1);
+        if (a.rstate) {
+          // back-off: a block that fails TWICE IN A ROW skips the attempt for 2, 4, 8, 16 iterations (the Gram product and the
+          // analysis are wasted work while the iterate still moves fast; late in a solve failures are isolated); a success resets it
+          if (outcome == 2) { const int lv = min(level + 1, 5); a.rstate[k] = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }
+          else a.rstate[k] = 0;
+        }
+      }
+    } else if (warm && a.refine != 0 && wait > 0 && tid == 0) {
+      a.rstate[k] = (level << 8) | (wait - 1);
+      if (a.stats) atomicAdd(&a.stats[7], 1);
+    }
+  }
+  if (refined) {
+    // eigenvalues on the diagonal of A, eigenvectors in V: nothing left to do before the reconstruction
+  } else
   if constexpr (PP) {
     // ---- ping-pong Jacobi: odd-even ordering on matrix POSITIONS (a rotation is followed by a swap of the two
     // positions, so pairs are always neighbours and no index tables exist).  Round type 0 pairs (2K, 2K+1), type 1
@@ -1190,7 +1468,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     }
     __syncthreads();
     const int npos = cnt[0] + cnt[2], nneg = cnt[1] + cnt[3];
-    const bool up = npos <= nneg;
+    const bool up = side_force != 0 ? side_force > 0 : npos <= nneg;
     if (tid < 128) {
       const bool me = up ? (l > 0.0) : (l < 0.0);
       const unsigned long long mk = __ballot(me);

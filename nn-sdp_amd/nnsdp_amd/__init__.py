@@ -4,7 +4,7 @@ from .methods import (  # noqa: F401
     FeedFwdNet, QcInputBox, QcSafety, QcReachHplane, QcReachCircle, QcReachEllipsoid,
     QcActivBounded, QcActivSector, SafetyQuery, ReachQuery, AdmmSdpOptions, QuerySolution,
     SingleDecomp, DoubleDecomp, DoubleRelaxDecomp, PathDecomp, DenseCone, Solver, SolverBatch,
-    runQuery, runQueries, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched, comm_unique_id, shardPlan,
+    runQuery, runQueries, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched, project_psd_warm, comm_unique_id, shardPlan,
 )
 from .frontend import (  # noqa: F401
     read_nnet, evalFeedFwdNet, evalFeedFwdNetBatch, sampleTrajs, randomNetwork, makeIntervalsInfo, makeQcActivs, approxEllipsoid,

@@ -40,7 +40,7 @@ class Options(C.Structure):
         ("max_time", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
         ("adapt_every", C.c_int32), ("check_every", C.c_int32), ("normalize", C.c_int32),
         ("warm_start", C.c_int32), ("proj_tol", C.c_double), ("polish", C.c_int32), ("cert_tol", C.c_double), ("verbose", C.c_int32), ("device", C.c_int32),
-        ("interval_guard", C.c_double), ("minv_mode", C.c_int32),
+        ("interval_guard", C.c_double), ("minv_mode", C.c_int32), ("proj_refine", C.c_int32),
     ]
 
 
@@ -53,6 +53,7 @@ class Result(C.Structure):
         ("t_setup", C.c_double), ("t_solve", C.c_double), ("t_total", C.c_double), ("t_eig", C.c_double),
         ("n_cliques", C.c_int32), ("max_clique", C.c_int32),
         ("eig_flops_per_iter", C.c_int64), ("eig_bytes_per_iter", C.c_int64), ("avg_sweeps", C.c_double), ("objective_admm", C.c_double), ("polish_shift", C.c_double),
+        ("refine_blocks", C.c_int64 * 4),
     ]
 
 
@@ -89,6 +90,7 @@ SYMBOLS = [
     ("nnsdp_eval_network", C.c_int, [C.c_int32, c_int32_p, c_double_p, C.c_int32, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("nnsdp_make_intervals", C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p] + [c_double_p] * 8),
     ("nnsdp_project_psd_batched", C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("nnsdp_project_psd_warm", C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p, c_int32_p, c_double_p]),
     ("nnsdp_comm_unique_id", C.c_int, [C.c_char_p]),
     ("nnsdp_shard_plan", C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("nnsdp_solver_set_comm", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),

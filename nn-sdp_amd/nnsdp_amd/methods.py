@@ -225,6 +225,7 @@ class AdmmSdpOptions:
     device: int = -1
     interval_guard: float = 5e-5   # relative floor on neuron interval half-widths inside the solver (see include/nnsdp.h)
     minv_mode: int = 0             # 0 auto, 1 dense M^-1, 2 structured M^-1 (block-banded by layer + low rank; see include/nnsdp.h)
+    proj_refine: bool = True       # GEMM-only refinement of the persistent eigenbasis in front of the Jacobi sweeps (see include/nnsdp.h)
 
     def to_c(self) -> _lib.Options:
         o = _lib.Options()
@@ -246,6 +247,7 @@ class AdmmSdpOptions:
         o.device = int(self.device)
         o.interval_guard = float(self.interval_guard)
         o.minv_mode = int(self.minv_mode)
+        o.proj_refine = int(bool(self.proj_refine))
         return o
 
 
@@ -361,7 +363,8 @@ def _solution(cp: _CProblem, r, bufs) -> QuerySolution:
     summary = dict(iters=r.iters, pres=r.pres, dres=r.dres, lambda_max=r.lambda_max, t_eig=r.t_eig,
                    n_cliques=r.n_cliques, max_clique=r.max_clique,
                    eig_flops_per_iter=r.eig_flops_per_iter, eig_bytes_per_iter=r.eig_bytes_per_iter,
-                   avg_sweeps=r.avg_sweeps, objective_admm=r.objective_admm, polish_shift=r.polish_shift)
+                   avg_sweeps=r.avg_sweeps, objective_admm=r.objective_admm, polish_shift=r.polish_shift,
+                   refine_blocks=[int(v) for v in r.refine_blocks])
     return QuerySolution(objective_value=r.objective, values=values,
                          termination_status=lib.nnsdp_status_string(r.status).decode(),
                          total_time=r.t_total, setup_time=r.t_setup, solve_time=r.t_solve, summary=summary)
@@ -650,3 +653,27 @@ def project_psd_batched(mats: Sequence[np.ndarray]):
         o += n * n
         eo += n
     return res, evs, ms.value
+
+
+def project_psd_warm(mats: Sequence[np.ndarray], bases: Sequence[np.ndarray], tol: float, refine: bool = True):
+    """The projection kernel in its warm form (test entry): bases[b] holds the eigenbasis kept from the previous projection of
+    block b (columns = eigenvectors).  Returns (projections, updated bases, outcome counts [converged, one refinement step,
+    sent on to the sweeps, not attempted], kernel milliseconds)."""
+    lib = _lib.load()
+    ns = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
+    flat = np.concatenate([np.asfortranarray(_f64(m)).ravel(order="F") for m in mats])
+    vb = np.concatenate([np.asfortranarray(_f64(v)).ravel(order="F") for v in bases])
+    if vb.shape != flat.shape:
+        raise ValueError("one basis per matrix, same shapes")
+    out = np.zeros_like(flat)
+    oc = np.zeros(4, dtype=np.int32)
+    ms = C.c_double()
+    _lib.check(lib.nnsdp_project_psd_warm(len(mats), ns.ctypes.data_as(_lib.c_int32_p), flat.ctypes.data_as(_lib.c_double_p),
+                                          vb.ctypes.data_as(_lib.c_double_p), float(tol), int(bool(refine)), out.ctypes.data_as(_lib.c_double_p),
+                                          oc.ctypes.data_as(_lib.c_int32_p), C.byref(ms)))
+    res, vs, o = [], [], 0
+    for n in ns:
+        res.append(out[o:o + n * n].reshape(n, n, order="F").copy())
+        vs.append(vb[o:o + n * n].reshape(n, n, order="F").copy())
+        o += n * n
+    return res, vs, oc.tolist(), ms.value

@@ -1,0 +1,128 @@
+"""The GEMM-only refinement stage of the PSD-projection kernel (nnsdp_options.proj_refine) against LAPACK, through the warm test entry
+nnsdp_project_psd_warm: the kernel exactly as the solver runs it from the second iteration on, with the eigenbasis of a PREVIOUS matrix
+as its starting point.  Reference of the arithmetic: numpy.linalg.eigh (the oracle's project_psd)."""
+import numpy as np
+import pytest
+
+import helpers  # noqa: F401
+import nnsdp_amd as na
+from oracle import admm as oadmm
+
+pytestmark = pytest.mark.gpu
+
+
+def _sym(rng, n, spectrum):
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return (Q * spectrum) @ Q.T, Q
+
+
+def _perturb(rng, A, eta):
+    D = rng.standard_normal(A.shape)
+    D = 0.5 * (D + D.T)
+    return A + eta * np.linalg.norm(A) / np.linalg.norm(D) * D
+
+
+@pytest.mark.parametrize("n", [27, 41, 57, 68, 85, 96])
+@pytest.mark.parametrize("eta", [1e-4, 1e-6])
+def test_one_refinement_step_meets_its_tolerance(n, eta):
+    """a slowly moving matrix (relative change eta, well separated spectrum): the stage takes its one-step path, and the projection is
+    within the level it promises - 30 x tol |A| - of LAPACK's; the sweeps-only kernel on the same input is the control"""
+    rng = np.random.default_rng(n)
+    spec = np.concatenate([np.linspace(0.2, 2.0, n // 2), -np.linspace(0.1, 1.5, n - n // 2)])
+    A0, Q0 = _sym(rng, n, spec)
+    A1 = _perturb(rng, A0, eta)
+    tol = 0.3 * eta
+    # (a converged 57-block rides along so that the launch uses the 1024-thread ping-pong variant, as a solver's launch with blocks of
+    # 27 and 68 does; the refinement stage lives in that variant)
+    C, QC = _sym(rng, 57, np.linspace(-1.0, 1.0, 57))
+    W, V, oc, _ = na.project_psd_warm([A1, C], [Q0, QC], tol, refine=True)
+    Wx = oadmm.project_psd(A1)
+    assert oc == [1, 1, 0, 0], oc
+    assert np.linalg.norm(W[0] - Wx) <= 30 * tol * np.linalg.norm(A1)
+    assert np.linalg.norm(V[0].T @ V[0] - np.eye(n)) <= 1e-3                 # orthogonal to second order in the rotation
+    Wj, Vj, ocj, _ = na.project_psd_warm([A1], [Q0], tol, refine=False)
+    assert ocj == [0, 0, 0, 0]
+    assert np.linalg.norm(Wj[0] - Wx) <= tol * np.linalg.norm(A1)
+
+
+def test_persistent_basis_over_many_steps_stays_accurate():
+    """the basis is never recomputed exactly: 40 consecutive small moves, each projection from the basis the previous call returned"""
+    rng = np.random.default_rng(7)
+    ns = [57, 68, 85]
+    mats, bases = [], []
+    for n in ns:
+        spec = np.concatenate([np.linspace(0.05, 2.0, n - n // 3), -np.linspace(0.05, 1.0, n // 3)])
+        A, Q = _sym(rng, n, spec)
+        mats.append(A)
+        bases.append(Q)
+    eta, tol = 3e-5, 1e-5
+    steps = 0
+    for it in range(40):
+        mats = [_perturb(rng, A, eta) for A in mats]
+        W, bases, oc, _ = na.project_psd_warm(mats, bases, tol, refine=True)
+        steps += oc[1]
+        for A, Wk, Vk in zip(mats, W, bases):
+            assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * tol * np.linalg.norm(A), it
+            assert np.linalg.norm(Vk.T @ Vk - np.eye(len(A))) <= 1e-3
+    assert steps >= 100          # nearly every visit took the one-step path (3 blocks x 40 calls)
+
+
+@pytest.mark.parametrize("case", ["near_zero_cluster", "degenerate_pairs", "large_move", "non_orthogonal_basis", "already_converged"])
+def test_refinement_edge_cases_fall_back_to_exact_sweeps(case):
+    rng = np.random.default_rng(11)
+    n = 68
+    tol = 1e-7
+    if case == "near_zero_cluster":
+        # many eigenvalues at the 1e-9 .. 1e-7 level around zero (the late-solve picture: rank X + rank Z = n): the rotations among
+        # them are large but their couplings are below the tolerance - the stage leaves them alone and still takes its step
+        spec = np.concatenate([np.linspace(0.3, 2.0, 30), 1e-8 * rng.standard_normal(18), -np.linspace(0.2, 1.0, 20)])
+        A0, Q0 = _sym(rng, n, spec)
+        A1 = _perturb(rng, A0, 1e-6)
+        expect_step = True
+    elif case == "degenerate_pairs":
+        # exactly repeated LARGE eigenvalues: first order cannot resolve rotations inside the eigenspaces, nor does it have to
+        spec = np.concatenate([np.repeat(np.linspace(0.5, 2.0, 17), 2), -np.repeat(np.linspace(0.3, 1.0, 17), 2)])
+        A0, Q0 = _sym(rng, n, spec)
+        A1 = _perturb(rng, A0, 1e-6)
+        expect_step = None          # either path; the result must be right
+    elif case == "large_move":
+        spec = np.concatenate([np.linspace(0.2, 2.0, 34), -np.linspace(0.1, 1.5, 34)])
+        A0, Q0 = _sym(rng, n, spec)
+        A1 = _perturb(rng, A0, 0.2)
+        expect_step = False
+    elif case == "non_orthogonal_basis":
+        spec = np.concatenate([np.linspace(0.2, 2.0, 34), -np.linspace(0.1, 1.5, 34)])
+        A0, Q0 = _sym(rng, n, spec)
+        A1 = _perturb(rng, A0, 0.05)                                      # too far for one step: the sweeps run ...
+        Q0 = Q0 @ (np.eye(n) + 1e-3 * rng.standard_normal((n, n)))       # ... from a basis that must first be re-orthogonalised
+        expect_step = False
+    else:
+        spec = np.concatenate([np.linspace(0.2, 2.0, 34), -np.linspace(0.1, 1.5, 34)])
+        A1, Q0 = _sym(rng, n, spec)
+        expect_step = None
+    W, V, oc, _ = na.project_psd_warm([A1], [Q0], tol, refine=True)
+    Wx = oadmm.project_psd(A1)
+    lim = (30 * tol if oc[1] else tol) * np.linalg.norm(A1) + 1e-12
+    assert np.linalg.norm(W[0] - Wx) <= lim, (case, oc, np.linalg.norm(W[0] - Wx) / np.linalg.norm(A1))
+    if expect_step is True:
+        assert oc[1] == 1, oc
+    if expect_step is False:
+        assert oc[2] == 1, oc
+        assert np.linalg.norm(V[0].T @ V[0] - np.eye(n)) <= 1e-9          # the sweeps got (and kept) an orthogonal basis
+    if case == "already_converged":
+        assert oc[0] == 1, oc
+
+
+def test_solver_with_and_without_refinement_agree():
+    """a whole solve: same optimum, the refinement stage carries most block visits late in the solve"""
+    q = helpers.product_query(helpers.load_problem("W40-D20", 0))
+    on = na.runQuery(q, na.AdmmSdpOptions(max_iters=60000, eps_rel=1e-6, decomp_mode=na.DoubleDecomp()))
+    off = na.runQuery(q, na.AdmmSdpOptions(max_iters=60000, eps_rel=1e-6, decomp_mode=na.DoubleDecomp(), proj_refine=False))
+    assert on.termination_status == off.termination_status == "OPTIMAL"
+    assert abs(on.summary["objective_admm"] - off.summary["objective_admm"]) <= 2e-5 * abs(off.summary["objective_admm"])
+    assert abs(on.summary["iters"] - off.summary["iters"]) <= 0.25 * off.summary["iters"]
+    print("solve seconds with / without the refinement stage:", on.solve_time, off.solve_time)
+    rb = on.summary["refine_blocks"]
+    assert off.summary["refine_blocks"] == [0, 0, 0, 0]
+    assert rb[1] > 0 and rb[0] + rb[1] + rb[2] + rb[3] > 0
+    print("refinement block visits [converged, one step, sweeps, skipped]:", rb, "iters", on.summary["iters"], off.summary["iters"])
