@@ -99,8 +99,10 @@ typedef struct nnsdp_options {
                              decomposition, three launches, O(ng b) bytes), 0 = auto (structured from 3500 kept multipliers on,
                              when the generator table has that structure) */
   int32_t proj_refine;    /* 1 (default): warm PSD blocks up to 96 first try the GEMM-only refinement of the eigenbasis kept from the
-                             previous iteration (one first-order rotation of all pairs on the matrix cores, accepted when its predicted
-                             off(A) is below 30 x the projection tolerance) and fall back to the exact Jacobi sweeps; 0: sweeps only */
+                             previous iteration (one rotation of all pairs to second order on the matrix cores, accepted when its predicted
+                             off(A) is below 30 x the projection tolerance) and fall back to the exact Jacobi sweeps; 2: blocks whose
+                             prediction misses by less than 30 x also take the step and are checked (B rebuilt, off(A) measured) before
+                             the sweeps - measured: no gain on W40-D20; 0: sweeps only */
 } nnsdp_options;
 
 /* Contents of Methods.QuerySolution (src/Methods/Methods.jl:46-55) plus solver diagnostics.
@@ -131,8 +133,8 @@ typedef struct nnsdp_result {
   double avg_sweeps;      /* Jacobi sweeps per block per iteration, averaged over the solve */
   double objective_admm;  /* objective of the raw ADMM iterate (before the polish) */
   double polish_shift;    /* diagonal shift applied by the polish in solver coordinates; -1: polish not applied */
-  int64_t refine_blocks[4]; /* projection refinement stage, block visits over the solve: already converged / one GEMM step / sent on to
-                             the Jacobi sweeps / attempt skipped (back-off after failures) */
+  int64_t refine_blocks[5]; /* projection refinement stage, block visits over the solve: already converged / one GEMM step / sent on to
+                             the Jacobi sweeps / attempt skipped (back-off after failures) / accepted after a checked step */
 } nnsdp_result;
 
 int nnsdp_version(void);
@@ -239,8 +241,8 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
 /* Test / diagnostic entry of the same kernel in its WARM form, as the solver runs it from the second iteration on: basis (in / out,
  * matrices back to back like mats, column-major, columns = eigenvectors) is the eigenbasis kept from the previous projection; tol
  * the relative stopping level off(V'AV) <= tol |A|_F; refine != 0 puts the GEMM-only refinement stage (nnsdp_options.proj_refine)
- * in front of the Jacobi sweeps.  outcome[4] (may be NULL) counts the blocks: converged as given / one refinement step / sent on to
- * the sweeps / not attempted.  Matrices up to 128.  Host pointers. */
+ * in front of the Jacobi sweeps (values as proj_refine).  outcome[5] (may be NULL) counts the blocks: converged as given / one
+ * refinement step / sent on to the sweeps / not attempted / accepted after a checked step.  Matrices up to 128.  Host pointers. */
 int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
                            int32_t* outcome, double* kernel_ms);
 

@@ -31,7 +31,7 @@ struct PathDecomp <: DecompMode end
   device::Int = -1
   interval_guard::Float64 = 5e-5
   minv_mode::Int = 0
-  proj_refine::Bool = true
+  proj_refine::Int = 1
 end
 
 # field order and types must match include/nnsdp.h
@@ -54,7 +54,7 @@ mutable struct CResult
   t_setup::Float64; t_solve::Float64; t_total::Float64; t_eig::Float64
   n_cliques::Int32; max_clique::Int32; eig_flops_per_iter::Int64; eig_bytes_per_iter::Int64; avg_sweeps::Float64
   objective_admm::Float64; polish_shift::Float64
-  refine_blocks::NTuple{4,Int64}
+  refine_blocks::NTuple{5,Int64}
 end
 
 function runQuery(query::Query, opts::AdmmSdpOptions)
@@ -92,7 +92,7 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   copts = COptions(mode, opts.max_iters, opts.eps_rel, opts.max_time, opts.sigma, opts.alpha, opts.adapt_every,
                    opts.check_every, opts.normalize, opts.warm_start, opts.proj_tol, opts.polish, opts.cert_tol, opts.verbose, opts.device, opts.interval_guard, opts.minv_mode, opts.proj_refine)
   res = CResult(pointer(gin), pointer(gout), pointer(gac1), pointer(gac2), pointer(Z),
-                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0, (0, 0, 0, 0))
+                0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0))
   GC.@preserve xdims M x1min x1max acymin acymax smin smax normal yc invP S gin gout gac1 gac2 Z begin
     p(v) = isempty(v) ? Ptr{Float64}(C_NULL) : pointer(v)
     prob = CProblem(ffnet.K, pointer(xdims), pointer(M), pointer(x1min), pointer(x1max), pointer(acymin), pointer(acymax),

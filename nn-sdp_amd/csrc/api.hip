@@ -446,7 +446,7 @@ struct nnsdp_solver {
     }
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
-    d_stats.alloc(8); d_stats.zero();
+    d_stats.alloc(12); d_stats.zero();
     d_rstate.alloc(std::max(ncl, 1)); d_rstate.zero();
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
     if (const char* e = std::getenv("NNSDP_REFINE_ACC")) refine_acc = std::atof(e);
@@ -1221,7 +1221,7 @@ struct nnsdp_solver {
     r->eig_bytes_per_iter = b;
     {
       std::vector<int> stv = d_stats.download();
-      for (int i = 0; i < 4; ++i) r->refine_blocks[i] = stv[4 + i];
+      for (int i = 0; i < 5; ++i) r->refine_blocks[i] = stv[4 + i];
       r->objective_admm = objective_admm;
     r->polish_shift = polished ? polish_shift : -1.0;
     r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
@@ -1841,7 +1841,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV;
   dcn.upload(cn); dco.upload(coff);
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot);
-  dst.alloc(8); dst.zero(); drs.alloc(batch); drs.zero();
+  dst.alloc(12); dst.zero(); drs.alloc(batch); drs.zero();
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
   const int alg = proj_algorithm(nmax);
@@ -1869,7 +1869,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   if (kernel_ms) *kernel_ms = ms;
   HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(basis, dV.p, tot * sizeof(double), hipMemcpyDeviceToHost));
-  if (outcome) { std::vector<int> st = dst.download(); for (int i = 0; i < 4; ++i) outcome[i] = st[4 + i]; }
+  if (outcome) { std::vector<int> st = dst.download(); for (int i = 0; i < 5; ++i) outcome[i] = st[4 + i]; }
   API_END
 }
 

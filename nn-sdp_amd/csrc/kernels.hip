@@ -61,10 +61,12 @@ struct ProjArgs {
   double* eig;            // packed eigenvalues (out, may be null)
   const double* kappa;    // device scalar: nu <- w + kappa (nu - w) (penalty change), may be null
   const double* tol_dev;  // device scalar overriding tol (lets the host adapt it between graph launches), may be null
-  int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen, [2..3] rotation counts, [4..7] refinement stage: blocks
-                          // accepted without a step / after one step / sent on to the sweeps / not attempted (back-off)
+  int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen, [2..3] rotation counts, [4..8] refinement stage: blocks
+                          // accepted without a step / after one unchecked step / sent on to the sweeps / not attempted (back-off) /
+                          // accepted after a checked step
   int warm;               // 1: use Vg as the starting basis
-  int refine;             // 1: warm blocks first try the GEMM-only refinement of the persistent basis (ping-pong variant only)
+  int refine;             // 1: warm blocks first try the GEMM-only refinement of the persistent basis (ping-pong variant only);
+                          // 2: also the checked form (step, rebuild B, measure) for blocks whose prediction fails by less than 30 x
   int* rstate;            // refinement back-off per block: (level << 8) | iterations still to skip (may be null)
   double refine_acc;      // a refinement step is accepted without a check when its PREDICTED off(A) is below refine_acc x tol |A|
   double refine_kcap;     // pairs whose first-order rotation angle B_ij / (d_j - d_i) exceeds this are left to the sweeps
@@ -593,63 +595,52 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
         __syncthreads();
       };
-      gram();
-      if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
-      double r2 = uniform(gram_diag());           // (two barriers inside: dvec / rdg are visible afterwards)
-      // analysis of the wave's pairs (i > j): nothing is written yet, so a rejected block reaches the sweeps untouched
       const double kcap = a.refine_kcap;
+      const double T = tolv * sqrt(fro2), accT = a.refine_acc * T;
+      double r2 = 0.0, off2 = 0.0, k2 = 0.0, unpp = 0.0, unnn = 0.0, unx = 0.0, kd2 = 0.0, cpos = 0.0, cneg = 0.0;
+      // analysis of the wave's pairs (i > j): nothing is written, so a rejected block reaches the sweeps untouched.
       // An unresolved coupling between two eigenvalues of the SAME sign costs nothing when the projection is rebuilt from the OTHER
       // side of the spectrum (W = sum over the positive side, or sym(nu) minus the sum over the negative side): the untouched side
       // only has to keep its inertia (b^2 < d_i d_j).  So the unresolved mass is kept per side and the side to rebuild from is the
       // smaller one when that passes, the other one when only that passes (measured on W40-D20 iterates at residual 4e-5: rejected
       // blocks 25 % -> 7 %; the near-degenerate pairs sit almost always among the negative eigenvalues).
-      double off2 = 0.0, k2 = 0.0, unpp = 0.0, unnn = 0.0, unx = 0.0, kd2 = 0.0;
+      auto analyse = [&]() {
+        double o2 = 0.0, q2 = 0.0, upp = 0.0, unn = 0.0, ux = 0.0, qd2 = 0.0;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        if (tti[m] >= 0)
+        for (int m = 0; m < 2; ++m)
+          if (tti[m] >= 0)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
-            if (i > j && i < n) {
-              const double b = A[i * lda + j], rr = -g[m][r];
-              const double li = dvec[i] * (1.0 + rdg[i]), lj = dvec[j] * (1.0 + rdg[j]);
-              const double gap = lj - li;
-              off2 += 2.0 * b * b;
-              if (fabs(b) <= kcap * fabs(gap) && gap != 0.0) {
-                const double e = (b + lj * rr) * rcp_nr2(gap), f = rr - e;
-                k2 += e * e + f * f;
-                kd2 += e * e * lj * lj + f * f * li * li;
-              } else {
-                k2 += 0.5 * rr * rr;
-                const double dd = dvec[i] * dvec[j];
-                if (b * b < dd) { if (dvec[i] > 0.0) unpp += 2.0 * b * b; else unnn += 2.0 * b * b; }   // same sign, inertia kept
-                else unx += 2.0 * b * b;
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+              if (i > j && i < n) {
+                const double b = A[i * lda + j], rr = -g[m][r];
+                const double li = dvec[i] * (1.0 + rdg[i]), lj = dvec[j] * (1.0 + rdg[j]);
+                const double gap = lj - li;
+                o2 += 2.0 * b * b;
+                if (fabs(b) <= kcap * fabs(gap) && gap != 0.0) {
+                  const double e = (b + lj * rr) * rcp_nr2(gap), f = rr - e;
+                  q2 += e * e + f * f;
+                  qd2 += e * e * lj * lj + f * f * li * li;
+                } else {
+                  q2 += 0.5 * rr * rr;
+                  const double dd = dvec[i] * dvec[j];
+                  if (b * b < dd) { if (dvec[i] > 0.0) upp += 2.0 * b * b; else unn += 2.0 * b * b; }   // same sign, inertia kept
+                  else ux += 2.0 * b * b;
+                }
               }
             }
-          }
-      off2 = uniform(block_sum(off2, red));
-      k2 = uniform(block_sum(k2, red));
-      unpp = uniform(block_sum(unpp, red));
-      unnn = uniform(block_sum(unnn, red));
-      unx = uniform(block_sum(unx, red));
-      kd2 = uniform(block_sum(kd2, red));
-      const double cpos = uniform(block_sum((tid < n && dvec[tid] > 0.0) ? 1.0 : 0.0, red));
-      const double cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
-      const double T = tolv * sqrt(fro2);
-      // predicted error of the projection after one step: second-order residual coupling |[E, K]| / 2 <= |E| |K| (measured: 0.3 |E| |K|
-      // at the median, 1.3 at the worst), the couplings left alone, and the third-order defect of exp(K) ~ I + K + K^2 / 2, which hits
-      // the projection as |K^3 D| / 3 <= |K|^2 |K D| / 3 (D = eigenvalues: large rotations between eigenvalues near zero cost nothing)
-      const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
-      const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);    // rebuilding from the positive / negative side
-      const bool prefer_pos = cpos <= cneg;
-      int outcome;      // 0: converged as it is, 1: one step, 2: on to the sweeps
-      if (off2 <= T * T && r2 <= tolv * tolv) outcome = 0;
-      else if (r2 > 1e-4) outcome = 2;
-      else if ((prefer_pos ? pred_pos : pred_neg) <= a.refine_acc * T) { outcome = 1; side_force = prefer_pos ? 1 : -1; }
-      else if ((prefer_pos ? pred_neg : pred_pos) <= a.refine_acc * T) { outcome = 1; side_force = prefer_pos ? -1 : 1; }
-      else outcome = 2;
-      if (outcome == 1) {
-        // E~ over B (both triangles and the diagonal), column sums for the second-order eigenvalues, V <- V (I + E~)
+        off2 = uniform(block_sum(o2, red));
+        k2 = uniform(block_sum(q2, red));
+        unpp = uniform(block_sum(upp, red));
+        unnn = uniform(block_sum(unn, red));
+        unx = uniform(block_sum(ux, red));
+        kd2 = uniform(block_sum(qd2, red));
+        cpos = uniform(block_sum((tid < n && dvec[tid] > 0.0) ? 1.0 : 0.0, red));
+        cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
+      };
+      // the step: X = E~ + E~^2 / 2 over B (both triangles and the diagonal), V <- V (I + X); with_sums: column sums of E~^2 and
+      // E~^2 d for the second-order eigenvalues (only the unchecked acceptance needs them)
+      auto step = [&](const bool with_sums) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
           if (tti[m] >= 0)
@@ -669,7 +660,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
               } else if (i == j) A[i * lda + i] = 0.5 * rdg[i];
             }
         __syncthreads();
-        {
+        if (with_sums) {
           const int col = tid >> 3, part = tid & 7;     // 8 lanes per column
           double s1 = 0.0, s2 = 0.0;
           if (col < n)
@@ -682,71 +673,34 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         // second-order term of the rotation: X = E~ + E~^2 / 2 ~ exp(K) - I, so that V (I + X) is orthogonal to THIRD order - with
         // the first-order step alone the projection carries an error |K^2 D| that no later iteration takes back.  E~^2 is symmetric
         // (E~ is antisymmetric up to R): lower tiles on the matrix cores, added to both triangles
-        {
-          d4_t sq[2];
+        d4_t sq[2];
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            d4_t c = {0.0, 0.0, 0.0, 0.0};
-            if (tti[m] >= 0) {
-              const double* ap = A + (16 * tti[m] + lr) * lda + lc;      // E~(i, k)
-              const double* bp = A + lc * lda + 16 * ttj[m] + lr;        // E~(k, j)
-              for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk * lda], c, 0, 0, 0);
-            }
-            sq[m] = c;
+        for (int m = 0; m < 2; ++m) {
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+          if (tti[m] >= 0) {
+            const double* ap = A + (16 * tti[m] + lr) * lda + lc;      // E~(i, k)
+            const double* bp = A + lc * lda + 16 * ttj[m] + lr;        // E~(k, j)
+            for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk * lda], c, 0, 0, 0);
           }
-          __syncthreads();
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            if (tti[m] >= 0)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
-                if (i < n && j < n) {
-                  if (i > j) { A[i * lda + j] += 0.5 * sq[m][r]; A[j * lda + i] += 0.5 * sq[m][r]; }
-                  else if (i == j) A[i * lda + i] += 0.5 * sq[m][r];
-                }
-              }
-          __syncthreads();
-        }
-        v_update();
-        {
-          const int col = tid >> 3, part = tid & 7;
-          double nr = 0.0;
-          if (col < n)
-            for (int rx = part; rx < n; rx += 8) { const double v = V[rx + (size_t)col * ldv]; nr += v * v; }
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) nr += __shfl_xor(nr, o, 8);
-          __syncthreads();      // every E~ entry has been read (the products above)
-          if (part == 0 && col < npg) {
-            double lamn = 0.0;
-            if (col < n) { const double d = dvec[col]; lamn = (d * (1.0 + rdg[col] + cs1[col]) - cs2[col]) / nr; }
-            A[col * lda + col] = lamn;
-          }
+          sq[m] = c;
         }
         __syncthreads();
-        refined = true;
-      } else if (outcome == 0) {
-        refined = true;
-      } else if (r2 > a.refine_acc * a.refine_acc * tolv * tolv) {
-        // (a defect below the error level accepted for refinement steps goes to the sweeps as it is: they diagonalise B exactly,
-        // the projection then carries that defect once, and the next refinement step's R term removes it)
-        // on to the sweeps, which keep V only as orthogonal as they find it: after refinement steps V is orthogonal to second order
-        // in E~, so it is first put right by Newton-Schulz steps V <- V (I + R / 2) (R -> 3/8 R^2 each), then B is rebuilt
-        for (int pass = 0; pass < 3 && r2 > 1e-24; ++pass) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
-            if (tti[m] >= 0)
+        for (int m = 0; m < 2; ++m)
+          if (tti[m] >= 0)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
-                if (i > j) { const double e = (i < n) ? -0.5 * g[m][r] : 0.0; A[i * lda + j] = e; A[j * lda + i] = e; }
-                else if (i == j) A[i * lda + i] = 0.5 * rdg[i];
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+              if (i < n && j < n) {
+                if (i > j) { A[i * lda + j] += 0.5 * sq[m][r]; A[j * lda + i] += 0.5 * sq[m][r]; }
+                else if (i == j) A[i * lda + i] += 0.5 * sq[m][r];
               }
-          __syncthreads();
-          v_update();
-          gram();
-          r2 = uniform(gram_diag());
-        }
+            }
+        __syncthreads();
+        v_update();
+      };
+      // B = V'AV again from the matrix in HBM (the A buffer held X)
+      auto rebuild_B = [&]() {
         for (int j = wv; j < npg; j += NW)
           for (int i = lane; i < npg; i += 64) {
             double v = 0.0;
@@ -755,13 +709,111 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           }
         __syncthreads();
         congruence();
+      };
+      // predicted error of the projection after one step: second-order residual coupling |[E, K]| / 2 <= |E| |K| (measured: 0.3 |E| |K|
+      // at the median, 1.3 at the worst), the couplings left alone, and the third-order defect of exp(K) ~ I + K + K^2 / 2, which hits
+      // the projection as |K^3 D| / 3 <= |K|^2 |K D| / 3 (D = eigenvalues: large rotations between eigenvalues near zero cost nothing).
+      // Round 0 looks at the block as it arrives.  A block whose prediction fails by less than 30 x takes the step anyway and is
+      // CHECKED: B is rebuilt with the new basis (round 1) and accepted when its measured off(B) is inside the accepted level - a
+      // third of the price of a sweep.  Whatever is left goes on to the exact sweeps from a valid (B, V).
+      int outcome = 2;      // 0: converged as it arrived, 1: one step (unchecked), 2: on to the sweeps, 3: step + check
+      gram();
+      if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
+      r2 = uniform(gram_diag());           // (two barriers inside: dvec / rdg are visible afterwards)
+      analyse();
+      bool check = false, far = true;      // far: the prediction missed by more than 10 x (the iterate still moves fast)
+      if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
+      else if (r2 <= 1e-4) {
+        const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
+        const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);    // rebuilding from the positive / negative side
+        const bool prefer_pos = cpos <= cneg;
+        if ((prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
+        else if ((prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
+        // (the checked form needs a step that is a rotation at all: |K|_F <= 0.3 keeps V (I + X) orthogonal to |K|^3 / 6 < 5e-3,
+        // which the Newton-Schulz repair below takes back if the check then fails)
+        else check = a.refine >= 2 && k2 <= 0.09 && fmin(pred_pos, pred_neg) <= 30.0 * accT;
+        far = fmin(pred_pos, pred_neg) > 10.0 * accT;
+      }
+      if (side_force != 0) {
+        step(true);
+        {
+          const int col = tid >> 3, part = tid & 7;
+          double nr = 0.0;
+          if (col < n)
+            for (int rx = part; rx < n; rx += 8) { const double v = V[rx + (size_t)col * ldv]; nr += v * v; }
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) nr += __shfl_xor(nr, o, 8);
+          if (part == 0 && col < npg) {
+            double lamn = 0.0;
+            if (col < n) { const double d = dvec[col]; lamn = (d * (1.0 + rdg[col] + cs1[col]) - cs2[col]) / nr; }
+            A[col * lda + col] = lamn;
+          }
+        }
+        __syncthreads();
+        outcome = 1;
+        refined = true;
+      } else if (check) {
+        // checked form: the step, B rebuilt with the new basis, accepted when the MEASURED off(B) and defect of V are inside the
+        // accepted level (the eigenvalues are then the diagonal of B itself)
+        step(false);
+        rebuild_B();
+        gram();
+        r2 = uniform(gram_diag());
+        double o2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if (tti[m] >= 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+              if (i > j && i < n) { const double b = A[i * lda + j]; o2 += 2.0 * b * b; }
+            }
+        off2 = uniform(block_sum(o2, red));
+        if (off2 <= accT * accT && r2 <= a.refine_acc * a.refine_acc * tolv * tolv) { outcome = 3; refined = true; }
+      }
+      if (!refined) {
+        outcome = 2;
+        if (!(r2 <= 0.01)) {
+          // (cannot happen with the guards above; Newton-Schulz only converges from |R| < 1) restart the block cold: V = I, B = sym(nu)
+          for (int j = wv; j < npg; j += NW)
+            for (int i = lane; i < npg; i += 64) {
+              double v = 0.0;
+              if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
+              A[i * lda + j] = v;
+              V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
+            }
+          __syncthreads();
+        } else if (r2 > a.refine_acc * a.refine_acc * tolv * tolv) {
+          // on to the sweeps, which keep V only as orthogonal as they find it: a defect above the error level accepted for refinement
+          // steps is first put right by Newton-Schulz steps V <- V (I + R / 2) (R -> 3/8 R^2 each), then B is rebuilt.  (A smaller
+          // one goes to the sweeps as it is: they diagonalise B exactly, the projection carries that defect once, and the next
+          // refinement step's R term removes it.)
+          for (int pass = 0; pass < 3 && r2 > 1e-24; ++pass) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              if (tti[m] >= 0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+                  if (i > j) { const double e = (i < n) ? -0.5 * g[m][r] : 0.0; A[i * lda + j] = e; A[j * lda + i] = e; }
+                  else if (i == j) A[i * lda + i] = 0.5 * rdg[i];
+                }
+            __syncthreads();
+            v_update();
+            gram();
+            r2 = uniform(gram_diag());
+          }
+          rebuild_B();
+        }
       }
       if (tid == 0) {
-        if (a.stats) atomicAdd(&a.stats[4 + outcome], 1);
+        if (a.stats) atomicAdd(&a.stats[outcome == 3 ? 8 : 4 + outcome], 1);
         if (a.rstate) {
-          // back-off: a block that fails TWICE IN A ROW skips the attempt for 2, 4, 8, 16 iterations (the Gram product and the
-          // analysis are wasted work while the iterate still moves fast; late in a solve failures are isolated); a success resets it
-          if (outcome == 2) { const int lv = min(level + 1, 5); a.rstate[k] = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }
+          // back-off: a block whose prediction misses by more than 10 x TWICE IN A ROW skips the attempt for 2, 4, 8, 16 iterations (the
+          // Gram product and the analysis are wasted work while the iterate still moves fast); near misses - the isolated failures
+          // late in a solve - try again at once; a success resets the level
+          if (outcome == 2 && far) { const int lv = min(level + 1, 5); a.rstate[k] = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }
+          else if (outcome == 2) a.rstate[k] = level << 8;
           else a.rstate[k] = 0;
         }
       }

@@ -53,7 +53,7 @@ class Result(C.Structure):
         ("t_setup", C.c_double), ("t_solve", C.c_double), ("t_total", C.c_double), ("t_eig", C.c_double),
         ("n_cliques", C.c_int32), ("max_clique", C.c_int32),
         ("eig_flops_per_iter", C.c_int64), ("eig_bytes_per_iter", C.c_int64), ("avg_sweeps", C.c_double), ("objective_admm", C.c_double), ("polish_shift", C.c_double),
-        ("refine_blocks", C.c_int64 * 4),
+        ("refine_blocks", C.c_int64 * 5),
     ]
 
 

@@ -225,7 +225,7 @@ class AdmmSdpOptions:
     device: int = -1
     interval_guard: float = 5e-5   # relative floor on neuron interval half-widths inside the solver (see include/nnsdp.h)
     minv_mode: int = 0             # 0 auto, 1 dense M^-1, 2 structured M^-1 (block-banded by layer + low rank; see include/nnsdp.h)
-    proj_refine: bool = True       # GEMM-only refinement of the persistent eigenbasis in front of the Jacobi sweeps (see include/nnsdp.h)
+    proj_refine: int = 1           # GEMM-only refinement of the persistent eigenbasis in front of the Jacobi sweeps: 0 off, 1, 2 (see include/nnsdp.h)
 
     def to_c(self) -> _lib.Options:
         o = _lib.Options()
@@ -247,7 +247,7 @@ class AdmmSdpOptions:
         o.device = int(self.device)
         o.interval_guard = float(self.interval_guard)
         o.minv_mode = int(self.minv_mode)
-        o.proj_refine = int(bool(self.proj_refine))
+        o.proj_refine = int(self.proj_refine)
         return o
 
 
@@ -657,8 +657,8 @@ def project_psd_batched(mats: Sequence[np.ndarray]):
 
 def project_psd_warm(mats: Sequence[np.ndarray], bases: Sequence[np.ndarray], tol: float, refine: bool = True):
     """The projection kernel in its warm form (test entry): bases[b] holds the eigenbasis kept from the previous projection of
-    block b (columns = eigenvectors).  Returns (projections, updated bases, outcome counts [converged, one refinement step,
-    sent on to the sweeps, not attempted], kernel milliseconds)."""
+    block b (columns = eigenvectors); refine as AdmmSdpOptions.proj_refine (True = 1).  Returns (projections, updated bases, outcome
+    counts [converged, one refinement step, sent on to the sweeps, not attempted, accepted after a checked step], kernel milliseconds)."""
     lib = _lib.load()
     ns = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
     flat = np.concatenate([np.asfortranarray(_f64(m)).ravel(order="F") for m in mats])
@@ -666,10 +666,10 @@ def project_psd_warm(mats: Sequence[np.ndarray], bases: Sequence[np.ndarray], to
     if vb.shape != flat.shape:
         raise ValueError("one basis per matrix, same shapes")
     out = np.zeros_like(flat)
-    oc = np.zeros(4, dtype=np.int32)
+    oc = np.zeros(5, dtype=np.int32)
     ms = C.c_double()
     _lib.check(lib.nnsdp_project_psd_warm(len(mats), ns.ctypes.data_as(_lib.c_int32_p), flat.ctypes.data_as(_lib.c_double_p),
-                                          vb.ctypes.data_as(_lib.c_double_p), float(tol), int(bool(refine)), out.ctypes.data_as(_lib.c_double_p),
+                                          vb.ctypes.data_as(_lib.c_double_p), float(tol), int(refine), out.ctypes.data_as(_lib.c_double_p),
                                           oc.ctypes.data_as(_lib.c_int32_p), C.byref(ms)))
     res, vs, o = [], [], 0
     for n in ns:

@@ -9,7 +9,7 @@ q = helpers.product_query(helpers.load_problem("W40-D20", 0))
 modes = [(na.DoubleDecomp(), "double"), (na.SingleDecomp(), "single")]
 modes = [m for m in modes if which in ("both", m[1])]
 for mode, nm in modes:
-    for rf, acc, kcap in ((False, 0, 0), (True, 30, 0.05), (True, 100, 0.05)):
+    for rf, acc, kcap in ((0, 0, 0), (1, 30, 0.05)):
         if rf:
             os.environ["NNSDP_REFINE_ACC"] = str(acc); os.environ["NNSDP_REFINE_KCAP"] = str(kcap)
         for cert in (0.0, 1e-3):
@@ -18,4 +18,4 @@ for mode, nm in modes:
             tot = max(sum(rb), 1)
             print(f"{nm:6s} refine {int(rf)} acc {acc:3d} kcap {kcap:4.2f} cert {cert:g}: {s.termination_status} iters {s.summary['iters']:6d} solve {s.solve_time:6.3f} s "
                   f"({1e6 * s.solve_time / s.summary['iters']:6.1f} us/it) rho {s.objective_value:.9f} admm {s.summary['objective_admm']:.9f} sweeps/block {s.summary['avg_sweeps']:.3f} "
-                  f"refine [conv {rb[0]} step {rb[1]} sweeps {rb[2]} ({100.0 * rb[2] / tot:.2f} %) skipped {rb[3]} ({100.0 * rb[3] / tot:.2f} %)]", flush=True)
+                  f"refine [conv {rb[0]} step {rb[1]} sweeps {rb[2]} ({100.0 * rb[2] / tot:.2f} %) skipped {rb[3]} ({100.0 * rb[3] / tot:.2f} %) checked {rb[4]}]", flush=True)

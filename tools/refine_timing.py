@@ -27,7 +27,7 @@ for ns in ([85] * 19, [68] * 20, [57, 85, 82, 79, 77, 73, 76, 77, 73, 64, 65, 76
 
 q = helpers.product_query(helpers.load_problem("W40-D20", 0))
 for mode, nm in ((na.SingleDecomp(), "single"), (na.DoubleDecomp(), "double")):
-    for rf in (True, False):
+    for rf in (2, 1, 0):
         s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=mode, max_iters=10 ** 9, proj_refine=rf))
         done = 0
         for upto in (2000, 5000, 10000, 15000, 30000):
