@@ -28,7 +28,9 @@ def main():
     q = helpers.product_query(helpers.load_problem(name, beta))
     res = {"rank": rank}
     # (a) exactly 300 plain iterations, then one check iteration
-    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()))
+    # (proj_refine=0 here and in the parent's serial run: the iterates are compared to 1e-8, and the refinement stage's accept /
+    # reject thresholds would amplify the 1e-9 difference of the two summation orders; legs (b), (c) run the default)
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), proj_refine=0))
     s.set_comm_callback(world, rank, allreduce)
     s.iterate(300)
     # diagnostics of the REPLICATED state: the Woodbury core applied to a fixed vector and the multiplier block after

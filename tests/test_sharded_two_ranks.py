@@ -31,7 +31,7 @@ def test_two_rank_sharded_solve_matches_the_serial_solve(name, beta, tmp_path):
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, name, str(beta), outs[r]]) for r in range(2)]
     # the serial solves run in this process meanwhile (3 processes on the card)
     q = helpers.product_query(helpers.load_problem(name, beta))
-    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()))
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), proj_refine=0))
     s.iterate(300)
     ref300 = s.residuals()
     s.close()
