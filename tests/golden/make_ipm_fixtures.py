@@ -45,13 +45,26 @@ def main():
         beta = int(beta)
         q = query_for(name, beta)
         t = time.time()
-        r = ipm.solve_query(q, ipm.IpmOptions(max_iters=500, tol_gap=1e-9, tol_feas=1e-9, verbose="-v" in os.environ.get("IPM_FLAGS", "")))
+        r = ipm.solve_query(q, ipm.IpmOptions(max_iters=int(os.environ.get("IPM_MAX_ITERS", "500")), tol_gap=1e-9, tol_feas=1e-9,
+                                              verbose="-v" in os.environ.get("IPM_FLAGS", "")))
         secs = time.time() - t
         pub = sorted(helpers.published_rho(name, beta))
+        # only converged runs are pins (tests/test_oracle_ipm.py iterates over ipm_optimum.json); a run that hit the iteration cap is
+        # kept apart with the bracket it reached
+        converged = r.status in ("OPTIMAL", "NEAR_OPTIMAL")
+        if not converged:
+            out_unc = os.path.join(helpers.GOLDEN, "ipm_unconverged.json")
+            unc = json.load(open(out_unc)) if os.path.exists(out_unc) else {}
+            unc[f"{name}_b{beta}"] = dict(net=name, beta=beta, rho=r.objective, lower=r.dual_objective, gap=float(r.gap), pinf=float(r.pinf), dinf=float(r.dinf),
+                                           lambda_max=r.lambda_max, status=r.status, iters=r.iters, secs=round(time.time() - t, 1), published=sorted(helpers.published_rho(name, beta)))
+            json.dump(unc, open(out_unc, "w"), indent=1, sort_keys=True)
+            print(c, "NOT CONVERGED", unc[f"{name}_b{beta}"], flush=True)
         res[f"{name}_b{beta}"] = dict(net=name, beta=beta, rho=r.objective, lower=r.dual_objective, gap=r.gap, pinf=r.pinf, dinf=r.dinf,
                                      lambda_max=r.lambda_max, status=r.status, iters=r.iters, secs=round(secs, 1), published=pub)
         print(c, res[f"{name}_b{beta}"], flush=True)
-        with open(os.path.join(ROOT, "profiles", f"r02_ipm_trace_{name}_b{beta}.csv"), "w", newline="") as fh:
+        if not converged:
+            del res[f"{name}_b{beta}"]
+        with open(os.path.join(ROOT, "profiles", f"{os.environ.get('IPM_ROUND', 'r03')}_ipm_trace_{name}_b{beta}.csv"), "w", newline="") as fh:
             w = csv.writer(fh)
             w.writerow(["it", "c_gamma", "lower_bound", "pinf", "dinf", "rel_gap", "mu"])
             for h in r.history:

@@ -1,7 +1,8 @@
 """End-to-end parity with EVERY kind of published row of the reference (dump/scale/*.csv -> tests/golden/dump_scale.csv):
 NnSdp.findEllipsoid on [0.5,1.5]^2 (experiments/scale.jl:26-27,70) through the product path only (native CROWN intervals,
-sampled ellipsoid, Double decomposition, residuals 1e-6, certificate polish), 19 (net, beta) rows with three OPTIMAL
-published values each, W in {10, 20}, D from 10 to 80, beta in {0, 3, 7}.
+sampled ellipsoid, Double decomposition, residuals 1e-6, certificate polish), 21 (net, beta) rows with three OPTIMAL
+published values each, W in {10, 20}, D from 10 to 100, beta in {0, 3, 7} - including W20-D100 beta = 0 and 7, the reference's
+headline rows (dump/scale/chordalsdp2-scale-I2-O2-W20-D100.nnet.csv:2,9).
 
 ONE stated tolerance:   |rho - nearest published| <= 1e-3 |rho| + 1e-9.
 Rows outside it are xfail(strict=True) with the measured relative distance (profiles/r02_parity_cause.csv) - they are not
@@ -33,6 +34,7 @@ ROWS = [
     ("W10-D80", 0, 7.3e-3),
     ("W20-D10", 0, 8.4e-3), ("W20-D10", 3, 9.4e-3), ("W20-D10", 7, 1.33e-2), ("W20-D20", 0, 1.7e-3),
     ("W20-D30", 0, 6.2e-3), ("W20-D30", 7, 1.5e-3), ("W20-D40", 0, 5.4e-3), ("W20-D50", 0, 2.3e-3), ("W20-D70", 0, 4.5e-3),
+    ("W20-D100", 0, 4.8e-3), ("W20-D100", 7, 3.9e-3),
 ]
 _cache = {}
 
