@@ -72,11 +72,30 @@ def cpu_baseline(workload: str, beta: int, seconds: float, gpu_iters_to_cert=Non
         n2, dt2 = rates["double"]
         out["double_decomp_iters_per_s"] = n2 / dt2
         if gpu_iters_to_cert:
-            # the port runs the very iteration of the GPU solver (iterates agree to 1e-13, tests/test_cpu_port.py), so its
-            # time to the same certificate is the GPU's iteration count over the CPU rate
-            out["time_to_cert_estimate_s"] = {k: v / (n2 / dt2) for k, v in gpu_iters_to_cert.items()}
-            out["time_to_cert_note"] = ("Double decomposition; iterations the GPU solve needed (same iteration, same stopping rule) divided by the "
-                                        "measured CPU rate: an estimate, the full CPU solve is not run inside the benchmark")
+            # the port runs the very iteration of the GPU solver (iterates agree to 1e-11, tests/test_cpu_port.py).  Its time to the
+            # certified-gap certificate is MEASURED: the port's loop (checks every 50 iterations, the oracle's penalty schedule) run
+            # for the iteration count the GPU's rule stopped at; for the 1e-6 rule (5x longer) the figure stays an estimate
+            need = gpu_iters_to_cert.get("certified_gap_1e-3")
+            if need:
+                Pd = oadmm.ScaledProblem(oop.build_operator(q, "double", normalize=True))
+                C = admm_c.CpuAdmm(Pd, 0.1, 1.6, threads=cores)
+                t1, it, next_adapt = time.time(), 0, 50
+                while it < need:
+                    r = C.step(50)
+                    it += 50
+                    if it >= next_adapt:
+                        next_adapt = max(it + 100, it * 3 // 2)
+                        ratio = np.sqrt(max(r["pres"], 1e-300) / max(r["dres"], 1e-300))
+                        if ratio > 1.5 or ratio < 0.67:
+                            C.S.nu, C.S.sigma = C.nu.copy(), C.sigma
+                            C.S.set_sigma(C.sigma * min(max(ratio, 0.2), 5.0))
+                            C.nu[:] = C.S.nu
+                            C.sigma = C.S.sigma
+                out["time_to_cert_s"] = {"certified_gap_1e-3": time.time() - t1}
+                out["time_to_cert_note"] = (f"measured: the C++/OpenMP port's loop (Double decomposition, {cores} threads) run for the {it} iterations after which the "
+                                            f"GPU's certified-gap rule stopped; iterate at the end: pres {r['pres']:.2e} dres {r['dres']:.2e} objective {r['objective']:.8g} "
+                                            "(the port has no certificate polish: 10 ms on the GPU)")
+            out["time_to_cert_estimate_s"] = {k: v / (n2 / dt2) for k, v in gpu_iters_to_cert.items() if k != "certified_gap_1e-3" or not need}
         return out
     except Exception as e:      # C++ port not built: numpy oracle
         out["port_error"] = repr(e)
@@ -102,6 +121,8 @@ def main():
     ap.add_argument("--burn-in", type=int, default=2000,
                     help="untimed ADMM iterations before the warmup so that the timed window sits in the solver's steady state "
                          "(a solve takes 16k-59k iterations; the first few hundred need 2-3 Jacobi sweeps per projection, the rest ~1)")
+    ap.add_argument("--late-burn-in", type=int, default=18000,
+                    help="further untimed iterations before a second timed window deep in the solve (reported as late_window; 0 = skip)")
     ap.add_argument("--workload", default="W40-D20")
     ap.add_argument("--beta", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -189,11 +210,33 @@ def main():
     soln = solver.finish()
     sm = soln.summary
 
-    # hipGraph replay rate of the same iteration (what nnsdp_solve itself uses)
-    tg0 = time.perf_counter()
-    solver.iterate(args.steps)          # every rank runs this too (sharded mode: collective inside)
+    # hipGraph replay rate of the same iteration (what nnsdp_solve itself uses): the graph is captured and instantiated by an untimed
+    # call first, and at least 256 iterations are timed whatever --steps is (a 20-step window used to contain the capture)
+    solver.iterate(64)                  # every rank runs these too (sharded mode: collective inside)
     torch.cuda.synchronize()
-    graph_ips = args.steps / (time.perf_counter() - tg0)
+    g_steps = max(args.steps, 256)
+    tg0 = time.perf_counter()
+    solver.iterate(g_steps)
+    torch.cuda.synchronize()
+    graph_ips = g_steps / (time.perf_counter() - tg0)
+    # the same measurement deep in the solve: a solve to residuals 1e-6 takes 59 000 iterations in this decomposition, and from about
+    # 10 000 on the projection kernel's refinement stage carries nearly every block (the sweeps are the early-phase path)
+    late = None
+    if args.late_burn_in > 0 and world == 1:
+        solver.advance(args.late_burn_in)
+        solver.iterate(args.warmup, time_eig=True)
+        torch.cuda.synchronize()
+        tl0 = time.perf_counter()
+        ms_l = solver.iterate(args.steps, time_eig=True)
+        torch.cuda.synchronize()
+        dtl = time.perf_counter() - tl0
+        solver.iterate(64)
+        torch.cuda.synchronize()
+        tl1 = time.perf_counter()
+        solver.iterate(g_steps)
+        torch.cuda.synchronize()
+        late = {"after_iters": args.burn_in + args.late_burn_in, "iters_per_s": args.steps / dtl, "kernel_avg_us": 1e3 * ms_l / args.steps,
+                "graph_replay_iters_per_s": g_steps / (time.perf_counter() - tl1)}
     solver.close()
 
     out = None
@@ -202,7 +245,7 @@ def main():
         # (tools/collect_profiles.sh), so the figure is read from the committed summary of the SAME workload and build round
         # and labelled as such; absent or for another workload it stays null
         traffic, traffic_source = None, None
-        pmc_file = os.path.join(ROOT, "profiles", f"r02_pmc_counters_{args.workload}.json")
+        pmc_file = os.path.join(ROOT, "profiles", f"r03_pmc_counters_{args.workload}.json")
         if args.beta == 0 and os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
@@ -242,13 +285,19 @@ def main():
                        "parallelism": ("clique-sharded, 1 all-reduce/iteration" if shard else "1 SDP per GPU, cliques batched in one launch")},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_proj_jacobi", "kernel_avg_us": eig_avg_s * 1e6,
+                         "kernel": "k_proj_jacobi (refinement stage + ping-pong sweeps, one launch)", "kernel_avg_us": eig_avg_s * 1e6,
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
                          "hbm_achieved_GBs": byts / eig_avg_s / 1e9, "hbm_frac": byts / eig_avg_s / 1e9 / HBM_PEAK_GBS},
             "eig_share_of_step": eig_avg_s / (dt / args.steps), "avg_jacobi_sweeps": sm["avg_sweeps"],
-            "graph_replay_iters_per_s": graph_ips,
+            "graph_replay_iters_per_s": graph_ips, "graph_replay_steps_timed": g_steps,
+            "refine_blocks_until_window": sm.get("refine_blocks"),
             "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
         }
+        if late:
+            fl = flops / (late["kernel_avg_us"] * 1e-6) / 1e12
+            late.update(roofline_frac=fl / FP64_PEAK_TFLOPS, achieved_TFLOPs=fl,
+                        note="second timed window of the same handle, same K steps and per-launch events; `value` and `roofline` above are the first window")
+            out["late_window"] = late
     if rank == 0 and world == 1 and not shard:
         # round 1's default window (5 warmup + 20 timed iterations of a FRESH solver, no burn-in), kept for a like-for-like
         # comparison with BENCH_r01.json: the first iterations of a solve are not the regime it spends its time in

@@ -3,13 +3,13 @@
 # aggregated into gpurun_out/profiles_new/ (copy into profiles/ afterwards).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BURN=2000; WARM=50; STEPS=200
-ARGS="--steps $STEPS --warmup $WARM --burn-in $BURN --batch 0 --no-cpu-baseline --cert-seconds 0"
+BURN=2000; WARM=50; STEPS=200; LATE=18000
+ARGS="--steps $STEPS --warmup $WARM --burn-in $BURN --late-burn-in $LATE --batch 0 --no-cpu-baseline --cert-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_$C.err
@@ -17,10 +17,10 @@ done
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_LDS -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_LDS.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_SQ.err || true
 cd $R
-python3 - "$OUT" "$TAG" $BURN $WARM $STEPS <<'PY'
+python3 - "$OUT" "$TAG" $BURN $WARM $STEPS $LATE <<'PY'
 import csv, collections, glob, json, sys, shutil
 out, tag = sys.argv[1], sys.argv[2]
-burn, warm, steps = (int(x) for x in sys.argv[3:6])
+burn, warm, steps, late = (int(x) for x in sys.argv[3:7])
 res = collections.defaultdict(dict)
 for path in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -41,8 +41,13 @@ for p in glob.glob(out + "/stats/*/*kernel_trace.csv"):
         d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(f) if "k_proj_jacobi" in r["Kernel_Name"])
     dur = [(e - s) / 1e3 for s, e in d]
     win = dur[burn + warm: burn + warm + steps]
+    # bench.py after the first window: 1 check iteration (residuals), 64 + max(steps, 256) graph-replay iterations, the late burn-in,
+    # the warm-up, then the late window
+    l0 = burn + warm + steps + 1 + 64 + max(steps, 256) + late + warm
+    lwin = dur[l0: l0 + steps]
     json.dump({"kernel": "k_proj_jacobi", "launches": len(dur), "avg_us_all_launches": sum(dur) / len(dur),
                "timed_window": {"first_launch": burn + warm, "launches": len(win), "avg_us": sum(win) / max(len(win), 1)},
+               "late_window": {"first_launch": l0, "launches": len(lwin), "avg_us": sum(lwin) / max(len(lwin), 1)},
                "burn_in_avg_us": sum(dur[:burn]) / max(burn, 1)},
               open(f"{out}/{tag}_kernel_trace_window.json", "w"), indent=1)
 k = [v for kk, v in res.items() if "k_proj_jacobi" in kk]
