@@ -173,6 +173,9 @@ int nnsdp_solver_apply_minv(nnsdp_solver* s, const double* q, double* out, int32
  * entry per multiplier of the problem (dropped multipliers 0).  In clique-sharded mode this block is replicated; the two-rank
  * test compares it bit for bit between ranks. */
 int nnsdp_solver_raw_multipliers(nnsdp_solver* s, double* out);
+/* diagnostic: what = 0 hipGraph launches so far, 1 whether an ncclAllReduce could be captured into a hipGraph (sharded mode over RCCL),
+ * 2 clique-sharded mode on, 3 iterations done, 4 PSD blocks, 5 largest block */
+int nnsdp_solver_info(nnsdp_solver* s, int32_t what, double* out);
 /* iterate until converged / limits; fills r like nnsdp_solve */
 int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r);
 int nnsdp_solver_finish(nnsdp_solver* s, nnsdp_result* r);
@@ -253,8 +256,12 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
  * and distributed by the host launcher (torch.distributed in bench.py --mode shard).  RCCL is dlopen'ed on
  * first use.  Independent SDPs need none of this (nnsdp_amd/parallel.py).  Every stopping / penalty / tolerance decision of
  * a sharded solve is taken from all-reduced numbers, so all ranks take it identically (including the time limit).
- * Covered by a two-process run on one GPU through nnsdp_solver_set_comm_callback (below; RCCL refuses two ranks on one
- * device) and a one-rank RCCL run; RCCL with more than one rank has not run yet (the build pool offers one GPU). */
+ * The replicated multiplier block is re-synchronised from rank 0 at every check iteration and the certificate (polish, eigmax) and
+ * the cert_tol stop are computed by rank 0 alone and broadcast, so all ranks return the same bits; nnsdp_solver_run / _finish are
+ * therefore COLLECTIVE calls in this mode.  Over RCCL the iterations between checks replay a hipGraph that contains the all-reduce
+ * (probed at set_comm; eager otherwise).  Covered by a two-process run on one GPU through nnsdp_solver_set_comm_callback (below;
+ * RCCL refuses two ranks on one device) and a one-rank RCCL run; RCCL with more than one rank has not run yet (the build pool
+ * offers one GPU). */
 int nnsdp_comm_unique_id(char* id128);
 /* Host-only (no GPU, no RCCL): the PSD blocks the solver works on for (problem, options) and their partition over `nranks`
  * ranks - exactly what nnsdp_solver_set_comm uses.  Two-pass: n_blocks first (block_n = start = NULL), then

@@ -336,6 +336,8 @@ struct nnsdp_solver {
   int nranks = 1, rank = 0, k0 = 0, k1 = 0;
   Rccl::Comm comm = nullptr;
   bool sharded = false;                // clique-sharded mode on (RCCL communicator or the caller's own all-reduce)
+  bool rccl_graph_ok = false;          // an ncclAllReduce on the solver's stream can be captured into a hipGraph and replayed (probed in set_comm)
+  long long graph_launches = 0;        // hipGraphLaunch calls so far (diagnostic, nnsdp_solver_info)
   nnsdp_allreduce_fn ar_fn = nullptr;  // caller's sum-all-reduce over host buffers (nnsdp_solver_set_comm_callback)
   void* ar_user = nullptr;
   std::vector<double> ar_host;
@@ -657,6 +659,28 @@ struct nnsdp_solver {
     if (so2.empty()) so2.push_back(0);
     d_sptr_own.upload(sp2); d_soff_own.upload(so2);
     hsum.alloc(S.NE);
+    hsum.zero();
+    // Can the exchange live inside a hipGraph?  Probed once, on this communicator and stream: capture one all-reduce of the
+    // consensus buffer, instantiate, replay.  If any step fails the sharded iteration stays eager (as in round 2); the
+    // callback transport synchronises with the host and can never be captured.
+    if (comm && !(std::getenv("NNSDP_NO_RCCL_GRAPH") && std::atoi(std::getenv("NNSDP_NO_RCCL_GRAPH")) != 0)) {
+      hipGraph_t pg = nullptr;
+      hipGraphExec_t pe = nullptr;
+      bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        Rccl& R = Rccl::get();
+        const int rc = R.AllReduce(hsum.p, hsum.p, (size_t)S.NE, Rccl::kFloat64, Rccl::kSum, comm, st);
+        const hipError_t ec = hipStreamEndCapture(st, &pg);          // always end the capture, whatever the call returned
+        ok = rc == 0 && ec == hipSuccess && pg != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&pe, pg, nullptr, nullptr, 0) == hipSuccess;
+      if (ok) ok = hipGraphLaunch(pe, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+      if (pe) (void)hipGraphExecDestroy(pe);
+      if (pg) (void)hipGraphDestroy(pg);
+      (void)hipGetLastError();
+      rccl_graph_ok = ok;
+      if (opt.verbose) std::fprintf(stderr, "[nnsdp] rank %d: ncclAllReduce inside a hipGraph: %s\n", rank, ok ? "captured and replayed" : "not capturable, eager iterations");
+    }
   }
 
   void allreduce(double* buf, size_t count) {
@@ -819,9 +843,12 @@ struct nnsdp_solver {
     while (left > 0) {
       bool can_warm = opt.warm_start != 0 && iters_done > 0 && since_cold < kColdPeriod;
       static const bool no_graph = [] { const char* e = std::getenv("NNSDP_NO_GRAPH"); return e && std::atoi(e) != 0; }();   // diagnostic: eager launches only
-      if (!no_graph && !sharded && big_idx.empty() && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
+      // (clique-sharded: only over RCCL and only when the probe in set_comm replayed a captured all-reduce; every rank takes the
+      // same branch - the counters deciding it are replicated - so the collective inside the graph is entered by all of them)
+      if (!no_graph && (!sharded || rccl_graph_ok) && big_idx.empty() && can_warm && left >= kGraphIters && kColdPeriod - since_cold >= kGraphIters) {
         build_graph(kGraphIters);
         HIPCHK(hipGraphLaunch(gexec, st));
+        ++graph_launches;
         since_cold += kGraphIters; iters_done += kGraphIters; left -= kGraphIters;
       } else {
         enqueue_iteration(false, next_is_warm());
@@ -1222,6 +1249,7 @@ struct nnsdp_solver {
     {
       std::vector<int> stv = d_stats.download();
       for (int i = 0; i < 5; ++i) r->refine_blocks[i] = stv[4 + i];
+      if (opt.verbose || std::getenv("NNSDP_REFINE_STATS")) std::fprintf(stderr, "[nnsdp] refinement rejections by dominant term: second/third order %d, cross-sign or indefinite pairs %d, same-sign pairs on both sides %d\n", stv[9], stv[10], stv[11]);
       r->objective_admm = objective_admm;
     r->polish_shift = polished ? polish_shift : -1.0;
     r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
@@ -1576,6 +1604,21 @@ int nnsdp_solver_raw_multipliers(nnsdp_solver* s, double* out) {
   if (s->S.ng) HIPCHK(hipMemcpy(h.data(), s->nu.p, (size_t)s->S.ng * sizeof(double), hipMemcpyDeviceToHost));
   for (int g = 0; g < s->P.ng; ++g) out[g] = 0.0;
   for (int g = 0; g < s->S.ng; ++g) out[s->S.keep[g]] = h[g];
+  API_END
+}
+
+int nnsdp_solver_info(nnsdp_solver* s, int32_t what, double* out) {
+  API_BEGIN
+  if (!s || !out) throw std::invalid_argument("null argument");
+  switch (what) {
+    case 0: *out = (double)s->graph_launches; break;
+    case 1: *out = s->rccl_graph_ok ? 1.0 : 0.0; break;
+    case 2: *out = s->sharded ? 1.0 : 0.0; break;
+    case 3: *out = (double)s->iters_done; break;
+    case 4: *out = (double)s->ncl; break;
+    case 5: *out = (double)s->nmax; break;
+    default: throw std::invalid_argument("unknown info item");
+  }
   API_END
 }
 

@@ -733,6 +733,10 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         // which the Newton-Schulz repair below takes back if the check then fails)
         else check = a.refine >= 2 && k2 <= 0.09 && fmin(pred_pos, pred_neg) <= 30.0 * accT;
         far = fmin(pred_pos, pred_neg) > 10.0 * accT;
+        if (side_force == 0 && tid == 0 && a.stats) {      // diagnostic: which term of the prediction rejected the block
+          const double ua = sqrt(unx), ub = sqrt(fmin(unpp, unnn));
+          atomicAdd(&a.stats[pred0 >= ua && pred0 >= ub ? 9 : (ua >= ub ? 10 : 11)], 1);
+        }
       }
       if (side_force != 0) {
         step(true);

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("nnsdp_solver_residuals", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("nnsdp_solver_apply_minv", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p, C.POINTER(C.c_int64)]),
     ("nnsdp_solver_raw_multipliers", C.c_int, [C.c_void_p, c_double_p]),
+    ("nnsdp_solver_info", C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     ("nnsdp_solver_run", C.c_int, [C.c_void_p, C.POINTER(Result)]),
     ("nnsdp_solver_finish", C.c_int, [C.c_void_p, C.POINTER(Result)]),
     ("nnsdp_solver_destroy", C.c_int, [C.c_void_p]),

@@ -460,6 +460,12 @@ class Solver:
         _lib.check(self.lib.nnsdp_solver_raw_multipliers(self.h, out.ctypes.data_as(_lib.c_double_p)))
         return out
 
+    def info(self, what: int) -> float:
+        """nnsdp_solver_info: 0 hipGraph launches, 1 RCCL all-reduce capturable into a hipGraph, 2 sharded, 3 iterations, 4 blocks, 5 largest block"""
+        v = C.c_double()
+        _lib.check(self.lib.nnsdp_solver_info(self.h, int(what), C.byref(v)))
+        return v.value
+
     def residuals(self):
         a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         _lib.check(self.lib.nnsdp_solver_residuals(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

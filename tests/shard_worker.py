@@ -32,7 +32,10 @@ def main():
     # reject thresholds would amplify the 1e-9 difference of the two summation orders; legs (b), (c) run the default)
     s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), proj_refine=0))
     s.set_comm_callback(world, rank, allreduce)
+    import time
+    t0 = time.perf_counter()
     s.iterate(300)
+    res["us_per_iter_sharded_callback"] = 1e6 * (time.perf_counter() - t0) / 300
     # diagnostics of the REPLICATED state: the Woodbury core applied to a fixed vector and the multiplier block after
     # 300 plain iterations (no check iteration yet, so no resynchronisation has happened), as hex digests the parent compares
     import hashlib

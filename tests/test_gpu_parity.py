@@ -5,6 +5,8 @@ Tolerances: fp64 throughout.  Assembly / adjoint: 1e-12 relative (different summ
 PSD projection: 1e-10 * |A| (Jacobi vs LAPACK).  Solver: the HIP ADMM and the oracle ADMM run the
 same iteration, so objectives agree to 1e-6 relative after the same number of iterations; against the
 reference's published MOSEK objective the tolerance is 1e-3 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -505,11 +507,25 @@ def test_clique_sharded_mode_single_rank_rccl():
     b = na.Solver(q, opts)
     b.set_comm(1, 0, na.comm_unique_id())
     b.iterate(250)
+    graphs = b.info(0), b.info(1)
     rb = b.residuals()
     sb = b.finish()
     b.close()
     assert np.allclose(ra, rb, rtol=1e-8, atol=1e-13), (ra, rb)
     assert np.isfinite(sb.objective_value)
+    # the sharded iteration replays a hipGraph with the ncclAllReduce inside it when this ROCm's RCCL can be captured (probed at set_comm)
+    print("RCCL all-reduce capturable into a hipGraph:", bool(graphs[1]), "- graph launches in 250 iterations:", int(graphs[0]))
+    assert (graphs[0] > 0) == bool(graphs[1])
+    import time
+    for capture in ("1", "0"):       # control-flow cost of the sharded iteration on one card: eager vs graph replay vs unsharded
+        os.environ["NNSDP_NO_RCCL_GRAPH"] = "0" if capture == "1" else "1"
+        e = na.Solver(helpers.product_query(helpers.load_problem("W40-D20", 0)), na.AdmmSdpOptions(max_iters=10 ** 8))
+        e.set_comm(1, 0, na.comm_unique_id())
+        e.iterate(600)
+        t0 = time.perf_counter(); e.iterate(800); dt = time.perf_counter() - t0
+        print(f"W40-D20 one-rank RCCL sharded iteration, all-reduce in hipGraph {capture}: {1e6 * dt / 800:.1f} us/iteration (graph launches {int(e.info(0))})")
+        e.close()
+    os.environ.pop("NNSDP_NO_RCCL_GRAPH", None)
     c = na.Solver(q, opts)
     c.iterate(5)
     with pytest.raises(na._lib.NnsdpError):
