@@ -408,11 +408,7 @@ struct nnsdp_solver {
       else big_idx.push_back(k);
     }
     if (!big_idx.empty()) {
-      std::vector<int> cs;
-      std::vector<long long> os;
-      for (int k : small_idx) { cs.push_back(cn[k]); os.push_back(coff[k]); }
-      if (cs.empty()) { cs.push_back(1); os.push_back(0); }
-      d_cn_s.upload(cs); d_coff_s.upload(os);
+      build_compact_lists(0, ncl);
       big_A.alloc((size_t)nmax * nmax); big_T.alloc((size_t)nmax * nmax); big_D.alloc(nmax); big_E.alloc(nmax);
       big_info.alloc(big_idx.size()); big_info.zero();
     }
@@ -512,6 +508,24 @@ struct nnsdp_solver {
     k0 = 0; k1 = ncl;
     t_setup = now_s() - t_create0;
   }
+
+  // blocks [lo, hi) this process projects (all of them, or the rank's range in clique-sharded mode), split into the ones the
+  // LDS-resident kernel takes in one launch (compact device lists) and the ones that go through the library path
+  std::vector<int> proj_small, proj_big;
+  int nmax_proj_small = 0;
+  void build_compact_lists(int lo, int hi) {
+    proj_small.clear(); proj_big.clear();
+    std::vector<int> cs;
+    std::vector<long long> os;
+    nmax_proj_small = 0;
+    for (int k = lo; k < hi; ++k) {
+      if (cn[k] <= 128) { proj_small.push_back(k); cs.push_back(cn[k]); os.push_back(coff[k]); nmax_proj_small = std::max(nmax_proj_small, cn[k]); }
+      else proj_big.push_back(k);
+    }
+    if (cs.empty()) { cs.push_back(1); os.push_back(0); }
+    d_cn_s.upload(cs); d_coff_s.upload(os);
+  }
+  int big_slot(int k) const { return (int)(std::find(big_idx.begin(), big_idx.end(), k) - big_idx.begin()); }
 
   static constexpr int kStructuredMinvFrom = 3500;   // auto mode: kept multipliers from which the structured M^-1 replaces the dense one (98 MB)
 
@@ -634,7 +648,6 @@ struct nnsdp_solver {
     if (nr < 1 || rk < 0 || rk >= nr || (!id128 && !fn)) throw std::invalid_argument("bad communicator arguments");
     if (iters_done != 0) throw std::invalid_argument("set_comm must be called before the first iteration");
     if (sharded) throw std::invalid_argument("the solver already has a communicator");
-    if (!big_idx.empty()) throw std::invalid_argument("clique-sharded mode needs every PSD block <= 128");
     if (fn) { ar_fn = fn; ar_user = user; }
     else {
       Rccl& R = Rccl::get();
@@ -646,6 +659,7 @@ struct nnsdp_solver {
     nranks = nr; rank = rk;
     std::vector<int> start = shard_ranges(cn, nr);
     k0 = start[rk]; k1 = start[rk + 1];
+    if (!big_idx.empty()) build_compact_lists(k0, k1);      // blocks above 128 (library path) are sharded like the others
     // source lists restricted to the owned cliques
     std::vector<int> sp = d_sptr.download();
     std::vector<long long> so = d_soff.download();
@@ -726,19 +740,26 @@ struct nnsdp_solver {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
     }
-    if (!small_idx.empty()) {
-      a.cn = d_cn_s.p; a.coff = d_coff_s.p; a.rstate = d_rstate.p;      // (compacted block list: the first small_idx.size() slots)
-      nnsdp::launch_proj(a, (int)small_idx.size(), nmax_small, v_lds, lds_bytes, st, proj_alg);
+    if (!proj_small.empty()) {
+      a.cn = d_cn_s.p; a.coff = d_coff_s.p; a.rstate = d_rstate.p;      // (compacted block list: the first proj_small.size() slots)
+      nnsdp::launch_proj(a, (int)proj_small.size(), nmax_small, v_lds, lds_bytes, st, proj_alg);
     }
-    for (size_t bi = 0; bi < big_idx.size(); ++bi) {
-      const int k = big_idx[bi];
+    enqueue_big_blocks(st);
+    HIPCHK(hipGetLastError());
+  }
+  // blocks above 128 of this process through the library path on stream s_ (the handle's stream is switched for the call: a batch
+  // handle runs them on ITS stream, in order behind the batched launch)
+  void enqueue_big_blocks(hipStream_t strm) {
+    if (proj_big.empty()) return;
+    if (strm != st) RBCHK(rocblas_set_stream(roc->h, strm));
+    for (int k : proj_big) {
       const int n = cn[k];
       double* nuk = nu.p + S.ng + coff[k];
       double* wk = w.p + S.ng + coff[k];
-      project_big_block(roc->h, st, n, nuk, wk, big_A.p, big_T.p, big_D.p, big_E.p, big_info.p + bi);
-      hipLaunchKernelGGL(k_big_rescale, dim3(cdiv((long long)n * n, 256)), dim3(256), 0, st, (long long)n * n, wk, nuk, d_kappa());
+      project_big_block(roc->h, strm, n, nuk, wk, big_A.p, big_T.p, big_D.p, big_E.p, big_info.p + big_slot(k));
+      hipLaunchKernelGGL(k_big_rescale, dim3(cdiv((long long)n * n, 256)), dim3(256), 0, strm, (long long)n * n, wk, nuk, d_kappa());
     }
-    HIPCHK(hipGetLastError());
+    if (strm != st) RBCHK(rocblas_set_stream(roc->h, st));
   }
 
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
@@ -1299,7 +1320,7 @@ struct nnsdp_batch {
   DBuf<ProjArgs> d_pw, d_pc;           // warm / cold projection arguments
   DBuf<int2> d_map;
   int nblocks = 0, nmax = 0, alg = 0;
-  bool v_lds = true, any_structured = false;
+  bool v_lds = true, any_structured = false, any_big = false;
   size_t lds = 0;
   int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
   hipGraph_t graph = nullptr;
@@ -1317,7 +1338,6 @@ struct nnsdp_batch {
     for (int i = 0; i < count; ++i) {
       if (!sv[i]) throw std::invalid_argument("null solver in batch");
       if (sv[i]->sharded) throw std::invalid_argument("clique-sharded solvers cannot be batched");
-      if (!sv[i]->big_idx.empty()) throw std::invalid_argument("solvers with PSD blocks above 128 cannot be batched");
       if (sv[i]->opt.device != sv[0]->opt.device) throw std::invalid_argument("batched solvers must live on one device");
       if (sv[i]->opt.check_every != sv[0]->opt.check_every) throw std::invalid_argument("batched solvers must share check_every");
       for (int j = 0; j < i; ++j) if (sv[j] == sv[i]) throw std::invalid_argument("a solver appears twice in the batch");
@@ -1338,7 +1358,7 @@ struct nnsdp_batch {
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
     nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = 0;
-    any_structured = false;
+    any_structured = false; any_big = false;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
       any_structured = any_structured || s->minv_structured;
@@ -1369,8 +1389,17 @@ struct nnsdp_batch {
       q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap;
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
-      for (int k = 0; k < s->ncl; ++k) map.push_back(make_int2((int)b, k));
-      nmax = std::max(nmax, s->nmax);
+      // blocks up to 128 of every SDP share ONE launch of the LDS-resident kernel; blocks above (the reference's 151-wide cliques of
+      // width-50 nets) follow per SDP through the library path on the batch's stream (eager: rocSOLVER is not captured into the graph)
+      if (s->big_idx.empty()) {
+        for (int k = 0; k < s->ncl; ++k) { map.push_back(make_int2((int)b, k)); nmax = std::max(nmax, s->cn[k]); }
+      } else {
+        // (the solver's compact list of its blocks up to 128, as its own launches use it: same slots, same back-off state)
+        pw.back().cn = s->d_cn_s.p; pw.back().coff = s->d_coff_s.p;
+        pc.back().cn = s->d_cn_s.p; pc.back().coff = s->d_coff_s.p;
+        for (size_t pos = 0; pos < s->proj_small.size(); ++pos) { map.push_back(make_int2((int)b, (int)pos)); nmax = std::max(nmax, s->cn[s->proj_small[pos]]); }
+        any_big = true;
+      }
       gx_gather = std::max(gx_gather, cdiv((long long)a.NE * kGatherLanes, kThreads));
       gx_at = std::max(gx_at, cdiv((long long)a.ng * 64, kThreads));
       gx_gemv = gx_at;
@@ -1379,6 +1408,7 @@ struct nnsdp_batch {
       gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
     }
     nblocks = (int)map.size();
+    nmax = std::max(nmax, 1);
     alg = proj_algorithm(nmax);
     v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
     lds = proj_lds_bytes(nmax, v_lds, alg);
@@ -1389,6 +1419,7 @@ struct nnsdp_batch {
   void enqueue_iteration(bool warm) {
     const int B = (int)act.size();
     if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
+    if (any_big) for (nnsdp_solver* s : act) s->enqueue_big_blocks(st);
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
     static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic
@@ -1412,7 +1443,7 @@ struct nnsdp_batch {
       const bool warm_ok = act[0]->opt.warm_start != 0 && sc < nnsdp_solver::kColdPeriod;
       int did;
       static const bool no_graph = [] { const char* e = std::getenv("NNSDP_NO_GRAPH"); return e && std::atoi(e) != 0; }();   // diagnostic: eager launches only
-      if (!no_graph && warm_ok && left >= kGraphIters && nnsdp_solver::kColdPeriod - sc >= kGraphIters) {
+      if (!no_graph && !any_big && warm_ok && left >= kGraphIters && nnsdp_solver::kColdPeriod - sc >= kGraphIters) {
         if (!gexec) {
           HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
           for (int i = 0; i < kGraphIters; ++i) enqueue_iteration(true);

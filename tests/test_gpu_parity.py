@@ -592,6 +592,27 @@ def test_blocks_above_128_width_50_safety_query_in_the_reference_cliques():
     # iteration differs from the oracle's - same optimum (test_decomposition_modes_agree); here: it runs and stays finite
     sd = na.runQuery(q, na.AdmmSdpOptions(max_iters=iters, decomp_mode=na.DoubleDecomp(), polish=False))
     assert sd.summary["max_clique"] == 151 and np.isfinite(sd.objective_value)
+    # the same query through the batch handle (two copies in lockstep: the 106-block of both in ONE launch of the LDS kernel, their
+    # 151-blocks through the library path on the batch's stream) and through the clique-sharded mode (one-rank RCCL): the iterates of
+    # the plain solve.  BASELINE config 5's shape in the reference's own decomposition, batched and sharded.
+    o = na.AdmmSdpOptions(max_iters=10 ** 8, decomp_mode=na.SingleDecomp(), proj_tol=1e-12, adapt_every=0, proj_refine=0)
+    ref = na.Solver(q, o)
+    ref.iterate(120)
+    r_ref = ref.residuals()
+    ref.close()
+    sb = na.SolverBatch([q, q], o)
+    sb.iterate(120)
+    for rr in sb.residuals():      # (the batch applies M^-1 through its tiled symmetric form: other rounding, and this transient amplifies it)
+        assert np.allclose(rr, r_ref, rtol=1e-6, atol=1e-9), (rr, r_ref)
+    sb.close()
+    sh = na.Solver(q, o)
+    sh.set_comm(1, 0, na.comm_unique_id())
+    sh.iterate(120)
+    r_sh = sh.residuals()
+    sh.close()
+    assert np.allclose(r_sh, r_ref, rtol=1e-6, atol=1e-9), (r_sh, r_ref)
+    bn, st = na.shardPlan(q, o, 2)
+    assert bn == [106, 151, 151, 151, 151] and st == [0, 3, 5]      # load-balanced by n^3: 106 + 151 + 151 | 151 + 151
 
 
 def _oracle_optimum():
