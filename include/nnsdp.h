@@ -225,6 +225,13 @@ int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const
                          double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
                          double* ymin, double* ymax);
 
+/* The same for either activation of the reference (ffnet.activ): activ = NNSDP_ACTIV_TANH restates auto_LiRPA's BoundTanh relaxation
+ * (exts/auto_LiRPA/operators/activation.py:843-1016, reached through exts/auto_lirpa_bridge.py:31-37,86-87) and fills smin / smax by
+ * makeSectorMinMax's tanh branch (src/Qc/activ_sector.jl:74-86: real slopes in [0, 1]).  activ = NNSDP_ACTIV_RELU is nnsdp_make_intervals. */
+int nnsdp_make_intervals_activ(int32_t K, const int32_t* xdims, const double* M, int32_t activ, const double* x1min, const double* x1max,
+                               double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
+                               double* ymin, double* ymax);
+
 /* Sampled forward pass on the GPU: Y[:, s] = ffnet(X[:, s]) for N points in fp64.  Replaces the
  * N = 1e5 calls of evalFeedFwdNet (src/MyNeuralNetwork/MyNeuralNetwork.jl:40-48) inside Utils.sampleTrajs (src/Utils/qc.jl:40-47),
  * whose outputs shape the ellipsoid of NnSdp.findEllipsoid (approxEllipsoid, src/Utils/qc.jl:50-67).  K, xdims, M as in

@@ -1751,11 +1751,12 @@ int nnsdp_make_cliques(int32_t K, const int32_t* xdims, int32_t beta, int32_t mo
   API_END
 }
 
-int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const double* x1min, const double* x1max,
+static int make_intervals_impl(int32_t K, const int32_t* xdims, const double* M, int32_t activ, const double* x1min, const double* x1max,
                          double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
                          double* ymin, double* ymax) {
   API_BEGIN
-  nnsdp::IntervalsOut iv = nnsdp::make_intervals(K, xdims, M, x1min, x1max);
+  if (activ != NNSDP_ACTIV_RELU && activ != NNSDP_ACTIV_TANH) throw std::invalid_argument("unknown activation");
+  nnsdp::IntervalsOut iv = nnsdp::make_intervals(K, xdims, M, x1min, x1max, activ == NNSDP_ACTIV_TANH);
   const double eps = 1e-4;   // src/Qc/activ_sector.jl:65
   size_t o = 0;
   for (int k = 1; k < K; ++k)
@@ -1765,14 +1766,33 @@ int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const
       const double pl = iv.plo[k - 1][i], pu = iv.phi[k - 1][i];
       if (acxmin) acxmin[o] = pl;
       if (acxmax) acxmax[o] = pu;
-      if (smin) smin[o] = pl > eps ? 1.0 : 0.0;
-      if (smax) smax[o] = pu < -eps ? 0.0 : 1.0;
+      if (activ == NNSDP_ACTIV_RELU) {
+        if (smin) smin[o] = pl > eps ? 1.0 : 0.0;
+        if (smax) smax[o] = pu < -eps ? 0.0 : 1.0;
+      } else {     // makeSectorMinMax, tanh branch (src/Qc/activ_sector.jl:74-86), including its 0/0 for a bound that is exactly 0
+        const double tl = std::tanh(pl) / pl, tu = std::tanh(pu) / pu;
+        const bool same = pl * pu >= 0.0;
+        if (smin) smin[o] = same ? tu : std::min(tl, tu);
+        if (smax) smax[o] = same ? tl : 1.0;
+      }
     }
   for (int i = 0; i < xdims[K]; ++i) {
     if (ymin) ymin[i] = iv.xlo[K][i];
     if (ymax) ymax[i] = iv.xhi[K][i];
   }
   API_END
+}
+
+int nnsdp_make_intervals(int32_t K, const int32_t* xdims, const double* M, const double* x1min, const double* x1max,
+                         double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
+                         double* ymin, double* ymax) {
+  return make_intervals_impl(K, xdims, M, NNSDP_ACTIV_RELU, x1min, x1max, acymin, acymax, acxmin, acxmax, smin, smax, ymin, ymax);
+}
+
+int nnsdp_make_intervals_activ(int32_t K, const int32_t* xdims, const double* M, int32_t activ, const double* x1min, const double* x1max,
+                               double* acymin, double* acymax, double* acxmin, double* acxmax, double* smin, double* smax,
+                               double* ymin, double* ymax) {
+  return make_intervals_impl(K, xdims, M, activ, x1min, x1max, acymin, acymax, acxmin, acxmax, smin, smax, ymin, ymax);
 }
 
 int nnsdp_eval_network(int32_t K, const int32_t* xdims, const double* M, int32_t activ, int64_t N, const double* X, double* Y,

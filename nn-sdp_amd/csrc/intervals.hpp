@@ -31,20 +31,74 @@ struct IntervalsOut {
   std::vector<std::vector<double>> plo, phi;      // K-1 pre-activation intervals (float64 interval step)
 };
 
-// backward bound of  Ws[L-1] relu(... relu(Ws[0] x + bs[0]) ...) + bs[L-1]  over the box [lo, hi];
+// ---- tanh relaxation (exts/auto_LiRPA/operators/activation.py BoundTanh: dtanh :863-868, precompute_relaxation :872-917,
+// bound_relax_impl, non-optimised branch :925-956,992-1016; the reference's bridge maps torch.nn.Tanh onto it,
+// exts/auto_lirpa_bridge.py:31-37,86-87).  float32 like the library's default dtype.
+inline float dtanh_f(float x) {
+  if (!(std::fabs(x) < 25.0f)) return 0.0f;        // (mask: cosh(25)^2 overflows float32)
+  const float c = std::cosh(x);
+  return 1.0f / (c * c);
+}
+// the table entries the relaxation looks up, computed on demand: tangent point d <= 0 whose tangent stays below tanh at
+// U = 0.01 (max(0, int(u / 0.01)) + 1), and its mirror image for the lower end (bisection, 100 halvings as the library's)
+inline float tanh_d_lower(float upper) {
+  const long idx = std::max(0L, (long)(upper / 0.01f)) + 1;
+  const float U = 0.01f * (float)idx, fU = std::tanh(U);
+  auto ok = [&](float d) { return dtanh_f(d) * (U - d) + std::tanh(d) <= fU; };
+  float l = -1.0f, r = 0.0f;
+  for (int it = 0; it < 64 && !ok(l); ++it) l *= 2.0f;
+  for (int it = 0; it < 100; ++it) { const float m = (l + r) / 2.0f; if (ok(m)) l = m; else r = m; }
+  return l;
+}
+inline float tanh_d_upper(float lower) {
+  const long idx = std::max(0L, (long)(lower / -0.01f)) + 1;
+  const float Lw = -0.01f * (float)idx, fL = std::tanh(Lw);
+  auto ok = [&](float d) { return dtanh_f(d) * (Lw - d) + std::tanh(d) >= fL; };
+  float l = 0.0f, r = 1.0f;
+  for (int it = 0; it < 64 && !ok(r); ++it) r *= 2.0f;
+  for (int it = 0; it < 100; ++it) { const float m = (l + r) / 2.0f; if (ok(m)) r = m; else l = m; }
+  return r;
+}
+// lw x + lb <= tanh(x) <= uw x + ub on [l, u]
+inline void tanh_relax(float l, float u, float& lw, float& lb, float& uw, float& ub) {
+  const float lower = std::max(l, -500.0f), upper = std::min(u, 500.0f);
+  const float yl = std::tanh(lower), yu = std::tanh(upper);
+  const float kd = (upper - lower) < 1e-6f ? dtanh_f(upper) : (yu - yl) / std::max(upper - lower, 1e-6f);
+  const bool pos = l >= 0.0f, neg = u <= 0.0f;
+  const float m = (lower + upper) / 2.0f, ym = std::tanh(m), km = dtanh_f(m);
+  lw = lb = uw = ub = 0.0f;
+  auto line = [](float k, float x0, float y0, float& w, float& b) { w += k; b += -x0 * k + y0; };
+  // (a neuron with l >= 0 and u <= 0, i.e. l = u = 0, carries BOTH masks in the library - mask_both = 1 - pos - neg = -1 there;
+  // the three contributions are added exactly as the library adds them)
+  const float fpos = pos ? 1.0f : 0.0f, fneg = neg ? 1.0f : 0.0f, fboth = 1.0f - fpos - fneg;
+  if (neg) { line(kd, lower, yl, uw, ub); line(km, m, ym, lw, lb); }
+  if (pos) { line(kd, lower, yl, lw, lb); line(km, m, ym, uw, ub); }
+  if (fboth != 0.0f) {
+    const float dl = tanh_d_lower(upper), du = tanh_d_upper(lower);
+    float w = 0.0f, b = 0.0f;
+    if (kd < dtanh_f(lower)) line(kd, lower, yl, w, b); else line(dtanh_f(dl), dl, std::tanh(dl), w, b);
+    lw += fboth * w; lb += fboth * b;
+    w = b = 0.0f;
+    if (kd < dtanh_f(upper)) line(kd, lower, yl, w, b); else line(dtanh_f(du), du, std::tanh(du), w, b);
+    uw += fboth * w; ub += fboth * b;
+  }
+}
+
+// backward bound of  Ws[L-1] act(... act(Ws[0] x + bs[0]) ...) + bs[L-1]  over the box [lo, hi] (act = relu, or tanh when tanh_act);
 // pre[j] = pre-activation bounds of layer j (j < L-1)
 inline void crown_backward(const std::vector<const DenseF*>& Ws, const std::vector<const std::vector<float>*>& bs,
                            const std::vector<std::vector<float>>& prel, const std::vector<std::vector<float>>& preu,
                            const std::vector<float>& lo, const std::vector<float>& hi, std::vector<float>& out_lo,
-                           std::vector<float>& out_hi) {
+                           std::vector<float>& out_hi, bool tanh_act = false) {
   const int L = (int)Ws.size();
   DenseF lA = *Ws[L - 1], uA = *Ws[L - 1];
   const int nout = lA.r;
   std::vector<float> lb(*bs[L - 1]), ub(*bs[L - 1]);
   for (int j = L - 2; j >= 0; --j) {
     const int d = lA.c;                       // width of layer j's output
-    std::vector<float> du(d), dl(d), bu(d);
+    std::vector<float> du(d), dl(d), bu(d), bl(d, 0.0f);
     for (int t = 0; t < d; ++t) {
+      if (tanh_act) { tanh_relax(prel[j][t], preu[j][t], dl[t], bl[t], du[t], bu[t]); continue; }
       float lr = std::min(prel[j][t], 0.0f);
       float ur = std::max(std::max(preu[j][t], 0.0f), lr + 1e-8f);
       du[t] = ur / (ur - lr);
@@ -55,8 +109,8 @@ inline void crown_backward(const std::vector<const DenseF*>& Ws, const std::vect
       float sl = 0.0f, su = 0.0f;
       for (int t = 0; t < d; ++t) {
         float a = lA.at(i, t), b = uA.at(i, t);
-        sl += std::min(a, 0.0f) * bu[t];
-        su += std::max(b, 0.0f) * bu[t];
+        sl += std::min(a, 0.0f) * bu[t] + std::max(a, 0.0f) * bl[t];
+        su += std::max(b, 0.0f) * bu[t] + std::min(b, 0.0f) * bl[t];
         lA.at(i, t) = std::max(a, 0.0f) * dl[t] + std::min(a, 0.0f) * du[t];
         uA.at(i, t) = std::max(b, 0.0f) * du[t] + std::min(b, 0.0f) * dl[t];
       }
@@ -93,7 +147,8 @@ inline void crown_backward(const std::vector<const DenseF*>& Ws, const std::vect
 }
 
 // M: K matrices [W_k b_k], column-major xdims[k+1] x (xdims[k]+1), back to back (include/nnsdp.h, nnsdp_problem::M)
-inline IntervalsOut make_intervals(int K, const int32_t* xdims, const double* M, const double* x1min, const double* x1max) {
+inline IntervalsOut make_intervals(int K, const int32_t* xdims, const double* M, const double* x1min, const double* x1max,
+                                   bool tanh_act = false) {
   if (K < 2 || !xdims || !M || !x1min || !x1max) throw std::invalid_argument("make_intervals: bad arguments");
   std::vector<DenseF> W(K);
   std::vector<std::vector<float>> b(K);
@@ -129,17 +184,17 @@ inline IntervalsOut make_intervals(int K, const int32_t* xdims, const double* M,
     std::vector<float> l, u;
     if (k < K) {
       // slice k (intervals_auto_lirpa.jl:12-28): pre-activation of layer k, then its post-activation through an identity head
-      crown_backward(Ws, bs, prel, preu, lo, hi, l, u);
+      crown_backward(Ws, bs, prel, preu, lo, hi, l, u, tanh_act);
       prel.push_back(l); preu.push_back(u);
       const int n = xdims[k];
       DenseF I(n, n);
       for (int i = 0; i < n; ++i) I.at(i, i) = 1.0f;
       std::vector<float> zero(n, 0.0f);
       Ws.push_back(&I); bs.push_back(&zero);
-      crown_backward(Ws, bs, prel, preu, lo, hi, l, u);
+      crown_backward(Ws, bs, prel, preu, lo, hi, l, u, tanh_act);
       fix(l, u);
     } else {
-      crown_backward(Ws, bs, prel, preu, lo, hi, l, u);
+      crown_backward(Ws, bs, prel, preu, lo, hi, l, u, tanh_act);
       fix(l, u);
     }
   }

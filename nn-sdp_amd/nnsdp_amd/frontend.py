@@ -142,8 +142,9 @@ def makeQcActivsIntvs(net: M.FeedFwdNet, x_intvs, acx_intvs, beta: int):
 
 # ----------------------------------------------------------------------------- f1: CROWN-sliced intervals
 def _intervals_native(x1min, x1max, net: M.FeedFwdNet):
-    """nnsdp_make_intervals (host C++ in the library, csrc/intervals.hpp): replaces the reference's per-layer
-    PyCall + ONNX + auto_LiRPA round trips (src/Intervals/intervals_auto_lirpa.jl:12-64)."""
+    """nnsdp_make_intervals_activ (host C++ in the library, csrc/intervals.hpp): replaces the reference's per-layer
+    PyCall + ONNX + auto_LiRPA round trips (src/Intervals/intervals_auto_lirpa.jl:12-64), ReLU and Tanh networks
+    (BoundRelu / BoundTanh relaxations, exts/auto_lirpa_bridge.py:31-37)."""
     lib = _lib.load()
     xd = np.asarray(net.xdims, dtype=np.int32)
     K = net.K
@@ -155,8 +156,8 @@ def _intervals_native(x1min, x1max, net: M.FeedFwdNet):
     acdim = int(xd[1:-1].sum())
     outs = [np.zeros(acdim) for _ in range(6)] + [np.zeros(int(xd[-1])) for _ in range(2)]
     dp = _lib.c_double_p
-    _lib.check(lib.nnsdp_make_intervals(K, xd.ctypes.data_as(_lib.c_int32_p), Mp.ctypes.data_as(dp), lo.ctypes.data_as(dp),
-                                        hi.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in outs]))
+    _lib.check(lib.nnsdp_make_intervals_activ(K, xd.ctypes.data_as(_lib.c_int32_p), Mp.ctypes.data_as(dp), M._activ_code(net.activ),
+                                              lo.ctypes.data_as(dp), hi.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in outs]))
     return outs
 
 
@@ -177,12 +178,9 @@ def makeIntervalsInfo(x1min, x1max, net: M.FeedFwdNet):
 
 def makeQcActivs(net: M.FeedFwdNet, x1min, x1max, beta: int):
     """Qc.makeQcActivs (src/Qc/activ.jl:45-72): bounded + sector QCs from the interval pre-processing."""
-    if M._activ_code(net.activ) != M.ACTIV_RELU:
-        # the native pre-processing restates auto_LiRPA's ReLU relaxation only; tanh networks go through interval arithmetic
-        return makeQcActivsIntvs(net, *intervalsWorstCase(x1min, x1max, net), beta)
     acymin, acymax, _, _, smin, smax, _, _ = _intervals_native(x1min, x1max, net)
     return [M.QcActivBounded(acymin=acymin, acymax=acymax),
-            M.QcActivSector(acxdim=len(acymin), beta=int(beta), smin=smin, smax=smax)]
+            M.QcActivSector(acxdim=len(acymin), beta=int(beta), smin=smin, smax=smax, activ=net.activ)]
 
 
 # ----------------------------------------------------------------------------- f2: callers of the path

@@ -43,7 +43,106 @@ def _concretize(A, bias, xl, xu, sign):
     return base - dev if sign < 0 else base + dev
 
 
-def _crown_linear_chain(Ws, bs, xl, xu, pre_bounds):
+def _dtanh(x):
+    """BoundTanh.dtanh (exts/auto_LiRPA/operators/activation.py:863-868), float32"""
+    x = np.asarray(x, dtype=np.float32)
+    mask = (np.abs(x) < np.float32(25.0)).astype(np.float32)
+    cosh = np.cosh(mask * x + np.float32(1) - mask)
+    return (mask * (np.float32(1) / (cosh * cosh))).astype(np.float32)
+
+
+def _tanh_tangent_points(lower, upper):
+    """d_lower / d_upper of BoundTanh.precompute_relaxation (activation.py:872-917), evaluated for the table entries the
+    relaxation looks up (:943-953): index = max(0, int(u / 0.01)) + 1 -> the tangent point d <= 0 whose tangent passes
+    below tanh at U = 0.01 index (bisection, 100 halvings, float32), and the mirror image for the lower end."""
+    f32 = np.float32
+    step = f32(0.01)
+    iu = np.maximum(0, (upper / step).astype(np.int64)) + 1
+    il = np.maximum(0, (lower / -step).astype(np.int64)) + 1
+    U = (step * iu.astype(np.float32)).astype(np.float32)
+    Lw = (-step * il.astype(np.float32)).astype(np.float32)
+
+    def check_lower(up, d):
+        return _dtanh(d) * (up - d) + np.tanh(d).astype(np.float32) <= np.tanh(up).astype(np.float32)
+
+    def check_upper(lo, d):
+        return _dtanh(d) * (lo - d) + np.tanh(d).astype(np.float32) >= np.tanh(lo).astype(np.float32)
+
+    l = -np.ones_like(U)
+    r = np.zeros_like(U)
+    for _ in range(64):
+        ok = check_lower(U, l)
+        if ok.all():
+            break
+        l = np.where(ok, l, l * f32(2)).astype(np.float32)
+    for _ in range(100):
+        m = ((l + r) / f32(2)).astype(np.float32)
+        ok = check_lower(U, m)
+        l = np.where(ok, m, l).astype(np.float32)
+        r = np.where(ok, r, m).astype(np.float32)
+    d_lower = l
+    l = np.zeros_like(U)
+    r = np.ones_like(U)
+    for _ in range(64):
+        ok = check_upper(Lw, r)
+        if ok.all():
+            break
+        r = np.where(ok, r, r * f32(2)).astype(np.float32)
+    for _ in range(100):
+        m = ((l + r) / f32(2)).astype(np.float32)
+        ok = check_upper(Lw, m)
+        l = np.where(ok, l, m).astype(np.float32)
+        r = np.where(ok, m, r).astype(np.float32)
+    d_upper = r
+    return d_lower, d_upper
+
+
+def _relax(l, u, activ):
+    """per-neuron linear relaxation lw x + lb <= act(x) <= uw x + ub on [l, u] (float32).
+    relu: exts/auto_LiRPA/operators/activation.py:306-323,386-388; tanh: BoundTanh.bound_relax_impl, the non-optimised branch
+    (:925-956, 992-1016), masks from :11-13."""
+    f32 = np.float32
+    if activ == "relu":
+        lb_r = np.minimum(l, f32(0))
+        ub_r = np.maximum(u, f32(0))
+        ub_r = np.maximum(ub_r, lb_r + f32(1e-8))
+        upper_d = ub_r / (ub_r - lb_r)
+        return (upper_d > f32(0.5)).astype(np.float32), np.zeros_like(upper_d), upper_d, -lb_r * upper_d
+    assert activ == "tanh"
+    lower = np.maximum(l, f32(-500)).astype(np.float32)
+    upper = np.minimum(u, f32(500)).astype(np.float32)
+    y_l, y_u = np.tanh(lower).astype(np.float32), np.tanh(upper).astype(np.float32)
+    close = (upper - lower) < f32(1e-6)
+    k_direct = np.where(close, _dtanh(upper), (y_u - y_l) / np.maximum(upper - lower, f32(1e-6))).astype(np.float32)
+    pos = (l >= 0).astype(np.float32)
+    neg = (u <= 0).astype(np.float32)
+    both = f32(1) - pos - neg
+    lw = np.zeros_like(lower); lb = np.zeros_like(lower); uw = np.zeros_like(lower); ub = np.zeros_like(lower)
+
+    def add(mask, kind, k, x0, y0):
+        nonlocal lw, lb, uw, ub
+        if kind == "lower":
+            lw = lw + mask * k; lb = lb + mask * (-x0 * k + y0)
+        else:
+            uw = uw + mask * k; ub = ub + mask * (-x0 * k + y0)
+
+    add(neg, "upper", k_direct, lower, y_l)
+    add(pos, "lower", k_direct, lower, y_l)
+    d_lower, d_upper = _tanh_tangent_points(lower, upper)
+    m = ((lower + upper) / f32(2)).astype(np.float32)
+    y_m, k_m = np.tanh(m).astype(np.float32), _dtanh(m)
+    add(neg, "lower", k_m, m, y_m)
+    add(pos, "upper", k_m, m, y_m)
+    md = both * (k_direct < _dtanh(lower)).astype(np.float32)
+    add(md, "lower", k_direct, lower, y_l)
+    add(both - md, "lower", _dtanh(d_lower), d_lower, np.tanh(d_lower).astype(np.float32))
+    md = both * (k_direct < _dtanh(upper)).astype(np.float32)
+    add(md, "upper", k_direct, lower, y_l)
+    add(both - md, "upper", _dtanh(d_upper), d_upper, np.tanh(d_upper).astype(np.float32))
+    return lw.astype(np.float32), lb.astype(np.float32), uw.astype(np.float32), ub.astype(np.float32)
+
+
+def _crown_linear_chain(Ws, bs, xl, xu, pre_bounds, activ="relu"):
     """Backward CROWN bounds of the output of linear layer len(Ws)-1 given the
     pre-activation bounds of all earlier layers.  Ws[j], bs[j] float32.
     Returns (lb, ub) float32."""
@@ -54,16 +153,11 @@ def _crown_linear_chain(Ws, bs, xl, xu, pre_bounds):
     ubias = bs[last].copy()
     for j in range(last - 1, -1, -1):
         l, u = pre_bounds[j]
-        lb_r = np.minimum(l, np.float32(0))
-        ub_r = np.maximum(u, np.float32(0))
-        ub_r = np.maximum(ub_r, lb_r + np.float32(1e-8))
-        upper_d = ub_r / (ub_r - lb_r)
-        upper_b = -lb_r * upper_d
-        lower_d = (upper_d > np.float32(0.5)).astype(np.float32)
+        lower_d, lower_b, upper_d, upper_b = _relax(l, u, activ)
         lA_pos, lA_neg = np.maximum(lA, 0), np.minimum(lA, 0)
         uA_pos, uA_neg = np.maximum(uA, 0), np.minimum(uA, 0)
-        lbias = lbias + lA_neg @ upper_b
-        ubias = ubias + uA_pos @ upper_b
+        lbias = lbias + lA_neg @ upper_b + lA_pos @ lower_b
+        ubias = ubias + uA_pos @ upper_b + uA_neg @ lower_b
         lA = lA_pos * lower_d[None, :] + lA_neg * upper_d[None, :]
         uA = uA_pos * upper_d[None, :] + uA_neg * lower_d[None, :]
         # through linear layer j
@@ -89,7 +183,8 @@ def crown_output_bounds(Ws64, bs64, x1min, x1max):
     return _crown_linear_chain(Ws, bs, xl, xu, pre_bounds), pre_bounds
 
 
-def intervals_crown_sliced(net: FeedFwdNet, x1min, x1max) -> IntervalsInfo:
+def intervals_crown_sliced(net: FeedFwdNet, x1min, x1max, activ: str = "relu") -> IntervalsInfo:
+    """activ = "tanh": the reference's bridge handles BoundTanh the same way (exts/auto_lirpa_bridge.py:31-37,86-87)"""
     x1min = np.asarray(x1min, dtype=np.float64)
     x1max = np.asarray(x1max, dtype=np.float64)
     K = net.K
@@ -105,18 +200,18 @@ def intervals_crown_sliced(net: FeedFwdNet, x1min, x1max) -> IntervalsInfo:
     xu32 = x1max.astype(np.float32)
     pre_bounds = []
     for k in range(1, K):
-        pre_bounds.append(_crown_linear_chain(W32[:k], b32[:k], xl32, xu32, pre_bounds))
+        pre_bounds.append(_crown_linear_chain(W32[:k], b32[:k], xl32, xu32, pre_bounds, activ))
         n = net.xdims[k]
         Wk = W32[:k] + [np.eye(n, dtype=np.float32)]
         bk = b32[:k] + [np.zeros(n, dtype=np.float32)]
-        lb, ub = _crown_linear_chain(Wk, bk, xl32, xu32, pre_bounds)
+        lb, ub = _crown_linear_chain(Wk, bk, xl32, xu32, pre_bounds, activ)
         lb = lb.astype(np.float64)
         ub = ub.astype(np.float64)
         lb = np.minimum(lb, ub)
         ub = np.maximum(lb, ub)
         x_intvs.append((lb, ub))
     # last slice = the full network
-    lb, ub = _crown_linear_chain(W32, b32, xl32, xu32, pre_bounds)
+    lb, ub = _crown_linear_chain(W32, b32, xl32, xu32, pre_bounds, activ)
     lb = lb.astype(np.float64)
     ub = ub.astype(np.float64)
     lb = np.minimum(lb, ub)

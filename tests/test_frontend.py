@@ -9,6 +9,7 @@ import pytest
 
 import helpers
 import nnsdp_amd as na
+from nnsdp_amd import frontend as F
 from oracle import intervals as ointv, nnet_io
 
 
@@ -171,3 +172,23 @@ def test_random_network_distribution():
     assert np.std(na.randomNetwork([3, 8, 2], sigma=0.5, seed=1).Ms[0]) == pytest.approx(0.5, rel=0.3)
     with pytest.raises(ValueError):
         na.randomNetwork([3])
+
+
+@pytest.mark.parametrize("xd,seed", [([2, 10, 10, 10, 10, 2], 0), ([3, 20, 20, 20, 4], 1), ([2, 40, 40, 40, 40, 40, 2], 2)])
+def test_native_tanh_intervals_match_the_oracle(xd, seed):
+    """nnsdp_make_intervals_activ with NNSDP_ACTIV_TANH (csrc/intervals.hpp, BoundTanh restated in C++) against oracle/intervals.py:
+    float32 summation order is the only difference (<= 2e-6); sector slopes by makeSectorMinMax's tanh branch."""
+    from oracle import intervals as oi, nnet_io
+    onet = nnet_io.random_net(xd, seed=seed)
+    net = na.FeedFwdNet(xdims=onet.xdims, Ms=onet.Ms, activ=na.methods.TanhActiv)
+    lo, hi = np.full(xd[0], 0.5), np.full(xd[0], 1.5)
+    iv = oi.intervals_crown_sliced(onet, lo, hi, "tanh")
+    x_intvs, acx = F.makeIntervalsInfo(lo, hi, net)
+    for (a, b), (c, d) in zip(x_intvs, iv.x_intvs):
+        assert np.abs(a - c).max() <= 2e-6 and np.abs(b - d).max() <= 2e-6
+    for (a, b), (c, d) in zip(acx, iv.acx_intvs):
+        assert np.abs(a - c).max() <= 2e-6 and np.abs(b - d).max() <= 2e-6
+    acymin, acymax, acxmin, acxmax, smin, smax, _, _ = F._intervals_native(lo, hi, net)
+    s0, s1 = F.makeSectorMinMax(acxmin, acxmax, na.methods.TanhActiv)
+    assert np.allclose(smin, s0, rtol=1e-13, atol=0) and np.allclose(smax, s1, rtol=1e-13, atol=0)      # (libm tanh vs numpy tanh: last bit)
+    assert np.all((smin > 0) & (smin <= 1) & (smax > 0) & (smax <= 1))
