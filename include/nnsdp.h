@@ -246,8 +246,9 @@ int nnsdp_eval_network(int32_t K, const int32_t* xdims, const double* M, int32_t
 
 /* Batched projection onto the PSD cone, the hot kernel (replaces the cone handling inside MOSEK;
  * reference of the arithmetic: LinearAlgebra.eigen on Symmetric).  mats: `batch` symmetric
- * matrices back to back, matrix b is n[b] x n[b] column-major.  Matrices up to 128 go through the LDS-resident Jacobi kernel
- * (one launch for all of them), larger ones (up to 4096) one at a time through rocSOLVER dsyevd + rocBLAS dgemm.  out receives
+ * matrices back to back, matrix b is n[b] x n[b] column-major.  Matrices up to 160 go through the LDS-resident Jacobi kernel
+ * (one launch for all of them; 129 .. 160 in its packed-triangle variant), larger ones (up to 4096) one at a time through rocSOLVER
+ * dsyevd + rocBLAS dgemm.  out receives
  * the projections, eigvals (may be NULL) sum(n) eigenvalues.  in/out are HOST pointers. */
 int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mats, double* out,
                               double* eigvals, double* kernel_ms);
@@ -256,7 +257,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
  * matrices back to back like mats, column-major, columns = eigenvectors) is the eigenbasis kept from the previous projection; tol
  * the relative stopping level off(V'AV) <= tol |A|_F; refine != 0 puts the GEMM-only refinement stage (nnsdp_options.proj_refine)
  * in front of the Jacobi sweeps (values as proj_refine).  outcome[5] (may be NULL) counts the blocks: converged as given / one
- * refinement step / sent on to the sweeps / not attempted / accepted after a checked step.  Matrices up to 128.  Host pointers. */
+ * refinement step / sent on to the sweeps / not attempted / accepted after a checked step.  Matrices up to 160.  Host pointers. */
 int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
                            int32_t* outcome, double* kernel_ms);
 

@@ -84,6 +84,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // 41..96, register-resident systolic sweeps for 97..128, LDS round robin for small blocks.
 // Diagnostic overrides: NNSDP_PROJ_ALG=0/1/2/3, NNSDP_BLOCK=1.
 static int proj_algorithm(int nmax) {
+  if (nnsdp::proj_packed_ok(nmax)) return nnsdp::kProjPacked;      // 129 .. 160: packed lower triangle in LDS (the only variant that fits)
   int alg = nnsdp::proj_pp_ok(nmax) ? nnsdp::kProjPingPong : (nnsdp::proj_sys_ok(nmax) ? nnsdp::kProjSystolic : nnsdp::kProjRoundRobin);
   if (const char* e = std::getenv("NNSDP_PROJ_ALG")) alg = std::atoi(e);
   if (const char* e = std::getenv("NNSDP_BLOCK")) { if (std::atoi(e) != 0) alg = nnsdp::kProjBlock; }
@@ -304,6 +305,7 @@ struct nnsdp_solver {
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
+  DBuf<double> Tg;
   DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc /* 8 control numbers | ng multipliers (sharded resync) */, gs;
   DBuf<double> accp;                    // per-workgroup partial sums of the residual quantities: [7][acc_stride]
   int acc_stride = 0, nb_upd = 0, nb_dual = 0, nb_obj = 0;
@@ -399,12 +401,12 @@ struct nnsdp_solver {
       nmax = std::max(nmax, cn[k]);
     }
     coff[ncl] = nmat;
-    // blocks up to 128 go to the LDS-resident Jacobi kernel (one launch for all of them); larger ones - the reference's
-    // 151-wide cliques of width-50 nets (chordal_cliques.jl:33-36), the single Zdim x Zdim cone of DeepSdpOptions
-    // (deep_sdp.jl:57) - are projected one at a time through rocSOLVER dsyevd + rocBLAS dgemm
+    // blocks up to 160 go to the LDS-resident Jacobi kernel (one launch for all of them; above 128 - the reference's 151-wide
+    // cliques of width-50 nets, chordal_cliques.jl:33-36 - in its packed variant); larger ones - the single Zdim x Zdim cone of
+    // DeepSdpOptions (deep_sdp.jl:57) - are projected one at a time through rocSOLVER dsyevd + rocBLAS dgemm
     nmax_small = 0;
     for (int k = 0; k < ncl; ++k) {
-      if (cn[k] <= 128) { small_idx.push_back(k); nmax_small = std::max(nmax_small, cn[k]); }
+      if (cn[k] <= nnsdp::kMaxLdsBlock) { small_idx.push_back(k); nmax_small = std::max(nmax_small, cn[k]); }
       else big_idx.push_back(k);
     }
     if (!big_idx.empty()) {
@@ -414,7 +416,7 @@ struct nnsdp_solver {
     }
     const int nsm = std::max(nmax_small, 1);
     proj_alg = proj_algorithm(nsm);
-    v_lds = proj_lds_bytes(nsm, true, proj_alg) <= 160 * 1024;
+    v_lds = proj_alg != nnsdp::kProjPacked && proj_lds_bytes(nsm, true, proj_alg) <= 160 * 1024;
     lds_bytes = proj_lds_bytes(nsm, v_lds, proj_alg);
     // gather sources: entry e <- (clique k, lower element (i,j))
     std::vector<int> sptr(S.NE + 1, 0);
@@ -487,6 +489,7 @@ struct nnsdp_solver {
     }
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
+    if (proj_alg == nnsdp::kProjPacked) { Tg.alloc(nmat); Tg.zero(); }      // warm-start scratch of the packed variant
     x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
     scal.alloc(4); acc.alloc(8 + (size_t)ng); acc.zero();
     nb_upd = cdiv(ng + nmat, kThreads);
@@ -519,7 +522,7 @@ struct nnsdp_solver {
     std::vector<long long> os;
     nmax_proj_small = 0;
     for (int k = lo; k < hi; ++k) {
-      if (cn[k] <= 128) { proj_small.push_back(k); cs.push_back(cn[k]); os.push_back(coff[k]); nmax_proj_small = std::max(nmax_proj_small, cn[k]); }
+      if (cn[k] <= nnsdp::kMaxLdsBlock) { proj_small.push_back(k); cs.push_back(cn[k]); os.push_back(coff[k]); nmax_proj_small = std::max(nmax_proj_small, cn[k]); }
       else proj_big.push_back(k);
     }
     if (cs.empty()) { cs.push_back(1); os.push_back(0); }
@@ -730,7 +733,7 @@ struct nnsdp_solver {
   void enqueue_proj(bool warm) {
     ProjArgs a;
     a.cn = d_cn.p + k0; a.coff = d_coff.p + k0; a.eoff = nullptr;
-    a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr;
+    a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr; a.Tg = Tg.p;
     a.kappa = d_kappa(); a.tol_dev = scal.p + 2; a.stats = d_stats.p;
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
@@ -1383,7 +1386,7 @@ struct nnsdp_batch {
       it.push_back(a);
       ProjArgs q;
       q.cn = s->d_cn.p; q.coff = s->d_coff.p; q.eoff = nullptr;
-      q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr;
+      q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
       q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap;
@@ -1410,6 +1413,9 @@ struct nnsdp_batch {
     nblocks = (int)map.size();
     nmax = std::max(nmax, 1);
     alg = proj_algorithm(nmax);
+    if (alg == nnsdp::kProjPacked)          // one launch for all members in the packed variant: every member needs its warm-start scratch
+      for (size_t b = 0; b < act.size(); ++b)
+        if (!act[b]->Tg.p) { act[b]->Tg.alloc(act[b]->nmat); act[b]->Tg.zero(); pw[b].Tg = pc[b].Tg = act[b]->Tg.p; }
     v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
     lds = proj_lds_bytes(nmax, v_lds, alg);
     if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
@@ -1855,7 +1861,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
     if (cn[b] < 1 || cn[b] > 4096) throw std::invalid_argument("matrix dimension must be in 1..4096");
     coff[b] = tot; eoff[b] = etot;
     tot += (long long)cn[b] * cn[b]; etot += cn[b];
-    if (cn[b] <= 128) nmax = std::max(nmax, cn[b]);
+    if (cn[b] <= nnsdp::kMaxLdsBlock) nmax = std::max(nmax, cn[b]);
   }
   coff[batch] = tot; eoff[batch] = etot;
   DBuf<int> dcn; DBuf<long long> dco, deo; DBuf<double> dnu, dw, dV, dE;
@@ -1868,7 +1874,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
-  a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p;
+  a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p; a.Tg = nullptr;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0;
   hipEvent_t e0, e1;
@@ -1879,7 +1885,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
     std::vector<int> cs, big;
     std::vector<long long> os, es;
     for (int b = 0; b < batch; ++b) {
-      if (cn[b] <= 128) { cs.push_back(cn[b]); os.push_back(coff[b]); es.push_back(eoff[b]); }
+      if (cn[b] <= nnsdp::kMaxLdsBlock) { cs.push_back(cn[b]); os.push_back(coff[b]); es.push_back(eoff[b]); }
       else big.push_back(b);
     }
     DBuf<int> dcs; DBuf<long long> dos, des;
@@ -1926,15 +1932,15 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   long long tot = 0;
   int nmax = 0;
   for (int b = 0; b < batch; ++b) {
-    if (cn[b] < 1 || cn[b] > 128) throw std::invalid_argument("matrix dimension must be in 1..128 (the LDS-resident kernel)");
+    if (cn[b] < 1 || cn[b] > nnsdp::kMaxLdsBlock) throw std::invalid_argument("matrix dimension must be in 1..160 (the LDS-resident kernel)");
     coff[b] = tot;
     tot += (long long)cn[b] * cn[b];
     nmax = std::max(nmax, cn[b]);
   }
   coff[batch] = tot;
-  DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV;
+  DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV, dT;
   dcn.upload(cn); dco.upload(coff);
-  dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot);
+  dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dT.alloc(tot);
   dst.alloc(12); dst.zero(); drs.alloc(batch); drs.zero();
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
@@ -1943,7 +1949,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a;
-  a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr;
+  a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
   a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05;
   if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);

@@ -59,6 +59,7 @@ struct ProjArgs {
   double* w;              // packed projections (out)
   double* Vg;             // packed eigenvectors (in for warm start, out)
   double* eig;            // packed eigenvalues (out, may be null)
+  double* Tg;             // scratch of the size of Vg for the packed variant's warm start (blocks 129 .. 160; may be null otherwise)
   const double* kappa;    // device scalar: nu <- w + kappa (nu - w) (penalty change), may be null
   const double* tol_dev;  // device scalar overriding tol (lets the host adapt it between graph launches), may be null
   int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen, [2..3] rotation counts, [4..8] refinement stage: blocks
@@ -216,6 +217,12 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   constexpr bool BLOCK = ALG == 1;
   constexpr bool SYS = ALG == 2;
   constexpr bool PP = ALG == 3;
+  // ALG = 4: blocks 129 .. 160 (the reference's 151-wide cliques of width-50 networks, chordal_cliques.jl:33-36).  The full matrix does
+  // not fit a CU's LDS beside anything else (160 x 161 doubles = 206 KB), its LOWER TRIANGLE does (103 KB), and the round-robin sweeps
+  // only ever touch that: same sweeps as ALG = 0 on a packed triangle, eigenvectors in HBM / L2, the warm-start congruence through a
+  // scratch matrix in HBM.
+  constexpr bool PK = ALG == 4;
+  static_assert(!PK || (!V_LDS && NT == 1024), "packed variant: V in HBM, 1024 threads");
   static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 5 || RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
   const int n = a.cn[k];
@@ -230,7 +237,10 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   // reuse the (then dead) A / V storage as exchange scratch whatever this block's own size is
   double* A = SYS ? lds + kSysHead : lds;
   // 2 buffers x half pair descriptors {c, s, (p, q), pad} = 4 doubles each, 16-byte aligned
-  double* desc = A + (PPL ? (size_t)nrow * kPpLdp : (((size_t)nrow * lda + 1) & ~(size_t)1));
+  double* desc = A + (PPL ? (size_t)nrow * kPpLdp : PK ? ((((size_t)npg * (npg + 1)) / 2 + 1) & ~(size_t)1) : (((size_t)nrow * lda + 1) & ~(size_t)1));
+  // element (i, j) of the lower triangle (i >= j) / of the symmetric matrix in the variant's storage
+  auto ixl = [&](int i, int j) { return PK ? ((i * (i + 1)) >> 1) + j : i * lda + j; };
+  auto ixs = [&](int i, int j) { return i >= j ? ixl(i, j) : ixl(j, i); };
   double* red = SYS ? lds : desc + (BLOCK ? 0 : 4 * npg);   // 16 doubles of reduction scratch (block mode: no pair descriptors)
   int* sel = reinterpret_cast<int*>(red + 16);  // npg + 2 ints: eigen-indices on the chosen side, counters
   double* V;
@@ -280,6 +290,15 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     if (tid < n) { const double v = A[tid * lda + tid]; fro2 += v * v; }
     fro2 = block_sum(fro2, red);
   } else {
+  if constexpr (PK) {
+    for (int j = tid >> 6; j < npg; j += NT >> 6)
+      for (int i = (tid & 63) + j; i < npg; i += 64) {
+        double v = 0.0;
+        if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
+        A[ixl(i, j)] = v;
+        fro2 += (i == j) ? v * v : 2.0 * v * v;
+      }
+  } else {
   for (int j = tid >> 6; j < npg; j += NT >> 6)
     for (int i = tid & 63; i < npg; i += 64) {
       double v = 0.0;
@@ -287,6 +306,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       A[i * lda + j] = v;
       fro2 += v * v;
     }
+  }
   fro2 = block_sum(fro2, red);
   // ---- starting basis
   if (V_LDS) {
@@ -376,6 +396,63 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   };
   if (warm && V_LDS) {
     congruence();
+  } else if (warm && PK) {
+    // A <- V' A V for the packed variant: T = A V into the HBM scratch (A read through the packed triangle), then the lower triangle of
+    // V' T straight into the packed storage; 4 x 2 register tiles, operands of the second product from HBM / L2
+    constexpr int kTiles = 4;                          // (160 / 4) * (160 / 2) = 3200 tiles over 1024 threads
+    const int ti_n = (n + 3) >> 2, tj_n = (n + 1) >> 1;
+    double* Tk = a.Tg + a.coff[k];
+    for (int m = 0; m < kTiles; ++m) {
+      const int t = tid + m * NT;
+      const int tj = t / ti_n, ti = t - tj * ti_n;
+      if (tj < tj_n) {
+        const int i0 = ti * 4, j0 = tj * 2;
+        const int i1 = min(i0 + 1, n - 1), i2 = min(i0 + 2, n - 1), i3 = min(i0 + 3, n - 1), j1 = min(j0 + 1, n - 1);
+        const double* v0 = V + (size_t)j0 * ldv;
+        const double* v1 = V + (size_t)j1 * ldv;
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        for (int l = 0; l < n; ++l) {
+          const double x0 = v0[l], x1 = v1[l];
+          const double y0 = A[ixs(i0, l)], y1 = A[ixs(i1, l)], y2 = A[ixs(i2, l)], y3 = A[ixs(i3, l)];
+          c0 += y0 * x0; c1 += y1 * x0; c2 += y2 * x0; c3 += y3 * x0;
+          d0 += y0 * x1; d1 += y1 * x1; d2 += y2 * x1; d3 += y3 * x1;
+        }
+        const double cc[4] = {c0, c1, c2, c3}, dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i0 + r < n) { Tk[(size_t)j0 * n + i0 + r] = cc[r]; if (j0 + 1 < n) Tk[(size_t)(j0 + 1) * n + i0 + r] = dd[r]; }
+      }
+    }
+    __syncthreads();     // (every read of A is done, and the block's writes of T are visible to the block)
+    for (int m = 0; m < kTiles; ++m) {
+      const int t = tid + m * NT;
+      const int tj = t / ti_n, ti = t - tj * ti_n;
+      if (tj < tj_n) {
+        const int i0 = ti * 4, j0 = tj * 2;
+        if (i0 + 3 >= j0) {                            // tiles with an entry on or below the diagonal
+          const int i1 = min(i0 + 1, n - 1), i2 = min(i0 + 2, n - 1), i3 = min(i0 + 3, n - 1), j1 = min(j0 + 1, n - 1);
+          const double *u0 = V + (size_t)i0 * ldv, *u1 = V + (size_t)i1 * ldv, *u2 = V + (size_t)i2 * ldv, *u3 = V + (size_t)i3 * ldv;
+          const double *t0 = Tk + (size_t)j0 * n, *t1 = Tk + (size_t)j1 * n;
+          double c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+          for (int l = 0; l < n; ++l) {
+            const double x0 = t0[l], x1 = t1[l];
+            const double y0 = u0[l], y1 = u1[l], y2 = u2[l], y3 = u3[l];
+            c0 += y0 * x0; c1 += y1 * x0; c2 += y2 * x0; c3 += y3 * x0;
+            d0 += y0 * x1; d1 += y1 * x1; d2 += y2 * x1; d3 += y3 * x1;
+          }
+          const double cc[4] = {c0, c1, c2, c3}, dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r;
+            if (i < n) {
+              if (i >= j0) A[ixl(i, j0)] = cc[r];
+              if (j0 + 1 < n && i >= j0 + 1) A[ixl(i, j0 + 1)] = dd[r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
   } else if (warm) {
     // (blocks too large to keep V in LDS) A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
     //   T = A V   (written over A),   A' = V' T   (written over T)
@@ -458,16 +535,17 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   const double thresh2 = uniform(tolv * tolv * fro2);  // converged when off(A) <= tol |A|_F, measured directly before each sweep
   const double rot_thr = uniform(0.5 * tolv * sqrt(fro2) / np);   // skipped elements together stay below tol/2
   int nrot = 0;
-  const int plane = tid - (NT - 64);            // lane index inside the parameter wave (>= 0 there)
+  constexpr int kParamLanes = PK ? 128 : 64;    // pair slots the parameter wave(s) can serve: half <= 64 up to n = 128, <= 80 in the packed variant (two waves)
+  const int plane = tid - (NT - kParamLanes);   // lane index inside the parameter wave(s) (>= 0 there)
   const int M = np - 1;                         // rounds per sweep
   // static work assignment (round independent, so the integer divisions happen once):
   //  * 2x2 blocks of the lower block triangle; block rows ia and half-1-ia are paired into rows of equal
   //    length half+1 and the rectangle ceil(half/2) x (half+1) is dealt out thread by thread
   //  * eigenvector units (pair slot, chunk of 32 rows) dealt out to 32-lane groups of all waves but the last
-  constexpr int MAXB = (NT == 1024) ? (V_LDS ? 2 : 3) : 9;   // ceil(ceil(half/2) * (half+1) / NT): half <= 48 with V in LDS
+  constexpr int MAXB = PK ? 4 : (NT == 1024) ? (V_LDS ? 2 : 3) : 9;   // ceil(ceil(half/2) * (half+1) / NT): half <= 48 with V in LDS, <= 80 packed
   // ceil(half * ceil(nv/32) / VG) for the sizes each variant is launched with (n <= 96 when V is in LDS)
-  constexpr int MAXU = (NT == 1024) ? (V_LDS ? 5 : 9) : 7;   // V in HBM: blocks up to n = 128
-  constexpr int VG = (NT - 64) / 32;
+  constexpr int MAXU = PK ? 15 : (NT == 1024) ? (V_LDS ? 5 : 9) : 7;   // V in HBM: blocks up to n = 128 (160 packed: 80 x 5 units over 28 groups)
+  constexpr int VG = (NT - kParamLanes) / 32;
   int blk[MAXB];
   {
     const int R = (half + 1) >> 1, Wd = half + 1;
@@ -1404,14 +1482,14 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     // direct measurement of off(A)^2 (no cancellation): ~1/40 of a sweep
     double off2 = 0.0;
     for (int j = tid >> 6; j < np; j += NT >> 6)
-      for (int i = (tid & 63) + j + 1; i < np; i += 64) { double v = A[i * lda + j]; off2 += v * v; }
+      for (int i = (tid & 63) + j + 1; i < np; i += 64) { double v = A[ixl(i, j)]; off2 += v * v; }
     off2 = 2.0 * block_sum(off2, red);
     if (off2 <= thresh2 || sweeps >= a.max_sweeps) break;
     // parameters of round 0
     if (plane >= 0 && plane < half) {
       int p = pair_top(plane, 0, M, half), q = pair_bot(plane, 0, M, half);
       double c, s;
-      jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], rot_thr, c, s);
+      jacobi_cs(A[ixl(p, p)], A[ixl(q, q)], A[ixs(p, q)], rot_thr, c, s);
       nrot += (s != 0.0);
       double* dd = desc + 4 * plane;
       dd[0] = c; dd[1] = s;
@@ -1424,34 +1502,37 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       long long tprev = clock64();
 #endif
       const double* dsc = desc + buf * 4 * half;
-      // phase 1: A <- J' A J on the lower block triangle
-      {
-        int e00[MAXB], e01[MAXB], e10[MAXB], e11[MAXB];
-        double b00[MAXB], b01[MAXB], b10[MAXB], b11[MAXB];
-        double2 r1[MAXB], r2[MAXB];
+      // phase 1: A <- J' A J on the lower block triangle (every 2x2 block is read and written by its one owner, so the blocks of a
+      // thread can be done in chunks: the packed variant holds 4 per thread and would spill with all of them in flight)
+      constexpr int CH = PK ? 2 : MAXB;
 #pragma unroll
-        for (int u = 0; u < MAXB; ++u) {
-          if (blk[u] >= 0) {
-            int ia = blk[u] >> 8, ib = blk[u] & 255;
+      for (int u0 = 0; u0 < MAXB; u0 += CH) {
+        int e00[CH], e01[CH], e10[CH], e11[CH];
+        double b00[CH], b01[CH], b10[CH], b11[CH];
+        double2 r1[CH], r2[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          if (blk[u0 + u] >= 0) {
+            int ia = blk[u0 + u] >> 8, ib = blk[u0 + u] & 255;
             const double* d1 = dsc + 4 * ia;
             const double* d2 = dsc + 4 * ib;
             r1[u] = *reinterpret_cast<const double2*>(d1);
             r2[u] = *reinterpret_cast<const double2*>(d2);
             int2 pq1 = *reinterpret_cast<const int2*>(d1 + 2), pq2 = *reinterpret_cast<const int2*>(d2 + 2);
-            e00[u] = sym_at(pq1.x, pq2.x, lda); e01[u] = sym_at(pq1.x, pq2.y, lda);
-            e10[u] = sym_at(pq1.y, pq2.x, lda); e11[u] = sym_at(pq1.y, pq2.y, lda);
+            e00[u] = ixs(pq1.x, pq2.x); e01[u] = ixs(pq1.x, pq2.y);
+            e10[u] = ixs(pq1.y, pq2.x); e11[u] = ixs(pq1.y, pq2.y);
             b00[u] = A[e00[u]]; b01[u] = A[e01[u]]; b10[u] = A[e10[u]]; b11[u] = A[e11[u]];
           }
         }
 #pragma unroll
-        for (int u = 0; u < MAXB; ++u) {
-          if (blk[u] >= 0) {
+        for (int u = 0; u < CH; ++u) {
+          if (blk[u0 + u] >= 0) {
             double c1 = r1[u].x, s1 = r1[u].y, c2 = r2[u].x, s2 = r2[u].y;
             double t00 = c1 * b00[u] - s1 * b10[u], t01 = c1 * b01[u] - s1 * b11[u];
             double t10 = s1 * b00[u] + c1 * b10[u], t11 = s1 * b01[u] + c1 * b11[u];
             double n00 = t00 * c2 - t01 * s2, n01 = t00 * s2 + t01 * c2;
             double n10 = t10 * c2 - t11 * s2, n11 = t10 * s2 + t11 * c2;
-            if ((blk[u] >> 8) == (blk[u] & 255)) { A[e00[u]] = n00; A[e11[u]] = n11; A[e01[u]] = 0.0; }
+            if ((blk[u0 + u] >> 8) == (blk[u0 + u] & 255)) { A[e00[u]] = n00; A[e11[u]] = n11; A[e01[u]] = 0.0; }
             else { A[e00[u]] = n00; A[e01[u]] = n01; A[e10[u]] = n10; A[e11[u]] = n11; }
           }
         }
@@ -1464,7 +1545,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         if (plane < half && r + 1 < M) {
           int p = pair_top(plane, r + 1, M, half), q = pair_bot(plane, r + 1, M, half);
           double c, s;
-          jacobi_cs(A[p * lda + p], A[q * lda + q], A[sym_at(p, q, lda)], rot_thr, c, s);
+          jacobi_cs(A[ixl(p, p)], A[ixl(q, q)], A[ixs(p, q)], rot_thr, c, s);
           nrot += (s != 0.0);
           double* dd = desc + (buf ^ 1) * 4 * half + 4 * plane;
           dd[0] = c; dd[1] = s;
@@ -1512,23 +1593,27 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 
   // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
   {
-    // selection list in index order, built by two waves with ballots (positions 0..127)
+    // selection list in index order, built by two (three: packed variant) waves with ballots (positions 0..127 / 0..191)
     const int nl = (SYS || PP) ? np : n;   // positions that can hold an eigenvalue (the padded one is exactly 0: never selected)
+    constexpr int kSelThreads = PK ? 192 : 128;
     int* cnt = reinterpret_cast<int*>(red);
     const int ln = tid & 63, w2 = tid >> 6;
     double l = 0.0;
-    if (tid < 128) {
-      if (tid < nl) l = A[tid * lda + tid];
+    if (tid < kSelThreads) {
+      if (tid < nl) l = A[ixl(tid, tid)];
       const unsigned long long bp = __ballot(l > 0.0), bn = __ballot(l < 0.0);
       if (ln == 0) { cnt[2 * w2] = __popcll(bp); cnt[2 * w2 + 1] = __popcll(bn); }
     }
+    if (!PK && tid == 0) { cnt[4] = 0; cnt[5] = 0; }
     __syncthreads();
-    const int npos = cnt[0] + cnt[2], nneg = cnt[1] + cnt[3];
+    const int npos = cnt[0] + cnt[2] + cnt[4], nneg = cnt[1] + cnt[3] + cnt[5];
     const bool up = side_force != 0 ? side_force > 0 : npos <= nneg;
-    if (tid < 128) {
+    if (tid < kSelThreads) {
       const bool me = up ? (l > 0.0) : (l < 0.0);
       const unsigned long long mk = __ballot(me);
-      const int rank = __popcll(mk & ((1ull << ln) - 1ull)) + (w2 == 1 ? (up ? cnt[0] : cnt[1]) : 0);
+      int before = 0;
+      for (int q = 0; q < w2; ++q) before += up ? cnt[2 * q] : cnt[2 * q + 1];
+      const int rank = __popcll(mk & ((1ull << ln) - 1ull)) + before;
       if (me) sel[rank] = tid;
     }
     if (tid == 0) { sel[npg] = up ? npos : nneg; sel[npg + 1] = up ? 1 : 0; }
@@ -1536,7 +1621,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   __syncthreads();
   const int nsel = sel[npg];
   const bool use_pos = sel[npg + 1] != 0;
-  if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[(tid + pofs) * lda + tid + pofs];
+  if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[ixl(tid + pofs, tid + pofs)];
   const double kap = a.kappa ? *a.kappa : 1.0;
   double* wk = a.w + a.coff[k];
   double* nuw = a.nu + a.coff[k];
@@ -1579,7 +1664,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         double s = 0.0;
         for (int t = 0; t < nsel; ++t) {
           int l = sel[t], lv = l - pofs;   // V in HBM is stored without the padded column
-          s += A[l * lda + l] * V[i + (size_t)lv * ldv] * V[j + (size_t)lv * ldv];
+          s += A[ixl(l, l)] * V[i + (size_t)lv * ldv] * V[j + (size_t)lv * ldv];
         }
         double nij = nuk[(size_t)j * n + i], nji = nuk[(size_t)i * n + j];
         if (!use_pos) s = 0.5 * (nij + nji) - s;
@@ -1615,7 +1700,9 @@ __global__ __launch_bounds__(NT) void k_proj_jacobi_b(const ProjArgs* __restrict
 //   kProjSystolic (default for 49 <= nmax <= 128): 512 threads, matrix + eigenvectors in registers
 //   kProjRoundRobin: LDS-resident round robin, NT = 1024 above kSmallBlock, 256 below (default for small blocks)
 //   kProjBlock: block Jacobi on MFMA (diagnostic; slower)
-enum { kProjRoundRobin = 0, kProjBlock = 1, kProjSystolic = 2, kProjPingPong = 3 };
+enum { kProjRoundRobin = 0, kProjBlock = 1, kProjSystolic = 2, kProjPingPong = 3, kProjPacked = 4 };
+static constexpr int kMaxLdsBlock = 160;      // largest block the LDS-resident kernel takes (packed variant); above: library path
+inline bool proj_packed_ok(int nmax) { return nmax > 128 && nmax <= kMaxLdsBlock; }
 static constexpr int kSmallBlock = 40;
 static constexpr int kSysMin = 49;
 inline bool proj_sys_ok(int nmax) { return nmax >= kSysMin && nmax <= 128; }
@@ -1623,9 +1710,11 @@ inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   
 #define NNSDP_PROJ_VARIANTS(X) \
   X((k_proj_jacobi<true, 1024, 1>)) X((k_proj_jacobi<true, 256, 1>)) X((k_proj_jacobi<true, 1024>)) X((k_proj_jacobi<false, 1024>)) \
   X((k_proj_jacobi<true, 256>)) X((k_proj_jacobi<false, 256>)) X((k_proj_jacobi<true, 512, 2, 6, 12>)) X((k_proj_jacobi<false, 512, 2, 8, 16>)) X((k_proj_jacobi<false, 512, 2, 7, 14>)) X((k_proj_jacobi<true, 1024, 3, 1, 5>)) X((k_proj_jacobi<true, 1024, 3, 1, 6>)) X((k_proj_jacobi<true, 1024, 3, 1, 7>)) \
+  X((k_proj_jacobi<false, 1024, 4>)) X((k_proj_jacobi_b<false, 1024, 4>)) \
   X((k_proj_jacobi_b<true, 1024>)) X((k_proj_jacobi_b<false, 1024>)) X((k_proj_jacobi_b<true, 256>)) X((k_proj_jacobi_b<false, 256>)) \
   X((k_proj_jacobi_b<true, 512, 2, 6, 12>)) X((k_proj_jacobi_b<false, 512, 2, 8, 16>)) X((k_proj_jacobi_b<false, 512, 2, 7, 14>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 5>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 6>)) X((k_proj_jacobi_b<true, 1024, 3, 1, 7>))
 inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
+  if (alg == kProjPacked) { hipLaunchKernelGGL((k_proj_jacobi<false, 1024, 4>), dim3(nblocks), dim3(1024), lds, st, a); return; }
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
     if (nmax <= 74) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 5>), dim3(nblocks), dim3(1024), lds, st, a);
     else if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
@@ -1654,6 +1743,7 @@ inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, si
 // batched form: `nblocks` blocks in total over the SDPs of a batch handle (device arrays args / map)
 inline void launch_proj_batched(const ProjArgs* dargs, const int2* dmap, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st,
                                 int alg) {
+  if (alg == kProjPacked) { hipLaunchKernelGGL((k_proj_jacobi_b<false, 1024, 4>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap); return; }
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
     if (nmax <= 74) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 5>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
     else if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi_b<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, dargs, dmap);
@@ -1684,6 +1774,8 @@ inline hipError_t proj_allow_big_lds() {
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
   int np = (nmax + 15) & ~15;
+  if (alg == kProjPacked)    // packed lower triangle, desc[2][half][4], red, sel
+    return ((((size_t)np * (np + 1)) / 2 + 1) + 4 * (size_t)np + 16 + (np >> 1) + 2 + 2) * sizeof(double);
   if (alg == kProjSystolic) {
     size_t am = ((size_t)np * (np + 1) + 1) & ~(size_t)1;
     size_t d = am + (v_lds ? (size_t)np * (np + 1) : 0);

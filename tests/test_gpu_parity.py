@@ -567,6 +567,29 @@ def test_blocks_above_128_dense_cone_w10_d20_tracks_oracle():
     assert abs(s0.objective_value - rho0) <= 1e-6 * abs(rho0) + 1e-12
 
 
+@pytest.mark.parametrize("n", [129, 151, 160])
+def test_packed_variant_blocks_129_to_160_warm_and_cold_against_lapack(n):
+    """blocks 129 .. 160 (the reference's 151-wide cliques) in the LDS-resident kernel's packed-triangle variant: cold start through
+    nnsdp_project_psd_batched and the warm form a solve uses (basis of the previous projection, HBM scratch for the congruence)"""
+    rng = np.random.default_rng(n)
+    spec = np.concatenate([np.linspace(0.05, 2.0, n - n // 3), -np.linspace(0.05, 1.0, n // 3)])
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A0 = (Q * spec) @ Q.T
+    P, ev, _ = na.project_psd_batched([A0, A0[:57, :57]])
+    for Pk, Ak in zip(P, (A0, A0[:57, :57])):
+        w, U = np.linalg.eigh(Ak)
+        assert np.abs(Pk - (U * np.maximum(w, 0)) @ U.T).max() <= 1e-10 * np.abs(Ak).max()
+    assert np.abs(np.sort(ev[0]) - spec[np.argsort(spec)]).max() <= 1e-10
+    for eta, tol in ((1e-3, 1e-6), (1e-6, 1e-9)):
+        D = rng.standard_normal((n, n)); D = 0.5 * (D + D.T)
+        A1 = A0 + eta * np.linalg.norm(A0) / np.linalg.norm(D) * D
+        W, V, oc, _ = na.project_psd_warm([A1], [Q], tol, refine=True)       # (the refinement stage lives in the ping-pong variant: ignored here)
+        w, U = np.linalg.eigh(A1)
+        assert np.linalg.norm(W[0] - (U * np.maximum(w, 0)) @ U.T) <= tol * np.linalg.norm(A1)
+        assert np.linalg.norm(V[0].T @ V[0] - np.eye(n)) <= 1e-10
+        assert oc == [0, 0, 0, 0, 0]
+
+
 def test_blocks_above_128_width_50_safety_query_in_the_reference_cliques():
     """the 5-50x6-5 (ACAS-Xu shaped) safety query in the reference's OWN Single / Double cliques (106, 151 x 4;
     chordal_cliques.jl:33-36) - blocks of 151 > 128: library path for those, LDS kernel for the rest - against the oracle."""
