@@ -300,7 +300,7 @@ struct nnsdp_solver {
   int ldm = 0;
   // device state
   DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate;
-  double refine_acc = 30.0, refine_kcap = 0.05;
+  double refine_acc = 30.0, refine_kcap = 0.05, refine_loose = 1.0;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -451,6 +451,7 @@ struct nnsdp_solver {
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
     if (const char* e = std::getenv("NNSDP_REFINE_ACC")) refine_acc = std::atof(e);
     if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) refine_kcap = std::atof(e);
+    if (const char* e = std::getenv("NNSDP_REFINE_LOOSE")) refine_loose = std::atof(e);
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -738,7 +739,7 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    a.refine = opt.proj_refine; a.rstate = d_rstate.p + k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap;
+    a.refine = opt.proj_refine; a.rstate = d_rstate.p + k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
@@ -1389,7 +1390,7 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
-      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap;
+      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap; q.refine_loose = s->refine_loose;
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       // blocks up to 128 of every SDP share ONE launch of the LDS-resident kernel; blocks above (the reference's 151-wide cliques of
@@ -1876,7 +1877,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p; a.Tg = nullptr;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
-  a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0;
+  a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0; a.refine_loose = 1.0;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
@@ -1951,7 +1952,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
-  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05;
+  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0;
   if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);
   if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) a.refine_kcap = std::atof(e);
   struct Events {

@@ -49,6 +49,12 @@ def test_two_rank_sharded_solve_matches_the_serial_solve(name, beta, tmp_path):
                 p.kill()
                 p.wait()
     r0, r1 = (json.load(open(o)) for o in outs)
+    os.makedirs(os.path.join(helpers.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(helpers.ROOT, "gpurun_out", f"shard_workers_{name}.json"), "w") as fh:      # post-mortem material
+        json.dump({"rank0": {k: v for k, v in r0.items() if k != "solve" and k != "cert"}, "solve0": {k: v for k, v in r0["solve"].items() if k != "gamma"},
+                   "solve1": {k: v for k, v in r1["solve"].items() if k != "gamma"}, "cert0": {k: v for k, v in r0["cert"].items() if k != "gamma"},
+                   "ref": [ref.termination_status, ref.summary["iters"], ref.summary["pres"], ref.summary["dres"]],
+                   "refc": [refc.termination_status, refc.summary["iters"]]}, fh, indent=1)
     # diagnostics of the replicated state, kept beside the run (gpurun_out/ travels back from the GPU box)
     diag = {k: [r0[k], r1[k]] for k in ("minv_digest", "mult300_digest", "mult301_digest")}
     # control-flow cost of the sharded iteration (two ranks on ONE card, gloo through host memory: an upper bound, not a scaling figure)
