@@ -678,6 +678,21 @@ struct nnsdp_solver {
     d_sptr_own.upload(sp2); d_soff_own.upload(so2);
     hsum.alloc(S.NE);
     hsum.zero();
+    // The Woodbury core is built per process by rocSOLVER / rocBLAS, and those do not return the same bits every time when several
+    // processes share a card (1 set-up in 20 under three-process contention, profiles/r03_contention_repro.log: every deviating
+    // solve had a different M^-1, every solve with the common M^-1 the same bits).  Rank 0's copy therefore replaces everybody's: the
+    // replicated operator is identical on all ranks by construction (one-time; the others contribute zeros to a sum).
+    {
+      std::vector<std::pair<double*, size_t>> bufs;
+      if (minv_structured) {
+        for (DBuf<double>* bf : {&m_P, &m_H, &m_HT, &m_Sc, &m_v, &m_kap}) if (bf->n) bufs.emplace_back(bf->p, bf->n);
+      } else if (Minv.n) bufs.emplace_back(Minv.p, Minv.n);
+      for (auto& bf : bufs) {
+        if (rank != 0) HIPCHK(hipMemsetAsync(bf.first, 0, bf.second * sizeof(double), st));
+        for (size_t off = 0; off < bf.second; off += (size_t)1 << 24) allreduce(bf.first + off, std::min(bf.second - off, (size_t)1 << 24));
+      }
+      HIPCHK(hipStreamSynchronize(st));
+    }
     // Can the exchange live inside a hipGraph?  Probed once, on this communicator and stream: capture one all-reduce of the
     // consensus buffer, instantiate, replay.  If any step fails the sharded iteration stays eager (as in round 2); the
     // callback transport synchronises with the host and can never be captured.
