@@ -301,6 +301,7 @@ struct nnsdp_solver {
   // device state
   DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate;
   double refine_acc = 30.0, refine_kcap = 0.05, refine_loose = 1.0;
+  int refine_pivots = 2;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -446,12 +447,13 @@ struct nnsdp_solver {
     }
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
-    d_stats.alloc(12); d_stats.zero();
+    d_stats.alloc(14); d_stats.zero();
     d_rstate.alloc(std::max(ncl, 1)); d_rstate.zero();
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
     if (const char* e = std::getenv("NNSDP_REFINE_ACC")) refine_acc = std::atof(e);
     if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) refine_kcap = std::atof(e);
     if (const char* e = std::getenv("NNSDP_REFINE_LOOSE")) refine_loose = std::atof(e);
+    if (const char* e = std::getenv("NNSDP_REFINE_PIVOTS")) refine_pivots = std::atoi(e);
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -754,7 +756,7 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    a.refine = opt.proj_refine; a.rstate = d_rstate.p + k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose;
+    a.refine = opt.proj_refine; a.rstate = d_rstate.p + k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_pivots = refine_pivots;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
@@ -1289,7 +1291,7 @@ struct nnsdp_solver {
     {
       std::vector<int> stv = d_stats.download();
       for (int i = 0; i < 5; ++i) r->refine_blocks[i] = stv[4 + i];
-      if (opt.verbose || std::getenv("NNSDP_REFINE_STATS")) std::fprintf(stderr, "[nnsdp] refinement rejections by dominant term: second/third order %d, cross-sign or indefinite pairs %d, same-sign pairs on both sides %d\n", stv[9], stv[10], stv[11]);
+      if (opt.verbose || std::getenv("NNSDP_REFINE_STATS")) std::fprintf(stderr, "[nnsdp] refinement rejections by dominant term: second/third order %d, cross-sign or indefinite pairs %d, same-sign pairs on both sides %d; exact pair rotations: %d before accepted steps, %d before rejected ones\n", stv[9], stv[10], stv[11], stv[12], stv[13]);
       r->objective_admm = objective_admm;
     r->polish_shift = polished ? polish_shift : -1.0;
     r->avg_sweeps = iters_done > 0 ? (double)stv[0] / ((double)iters_done * ncl) : 0.0;
@@ -1405,7 +1407,7 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
-      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap; q.refine_loose = s->refine_loose;
+      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap; q.refine_loose = s->refine_loose; q.refine_pivots = s->refine_pivots;
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       // blocks up to 128 of every SDP share ONE launch of the LDS-resident kernel; blocks above (the reference's 151-wide cliques of
@@ -1892,7 +1894,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p; a.Tg = nullptr;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
-  a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0; a.refine_loose = 1.0;
+  a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0; a.refine_loose = 1.0; a.refine_pivots = 0;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, nullptr));
@@ -1957,7 +1959,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV, dT;
   dcn.upload(cn); dco.upload(coff);
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dT.alloc(tot);
-  dst.alloc(12); dst.zero(); drs.alloc(batch); drs.zero();
+  dst.alloc(14); dst.zero(); drs.alloc(batch); drs.zero();
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
   const int alg = proj_algorithm(nmax);
@@ -1967,9 +1969,10 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   ProjArgs a;
   a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
-  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0;
+  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0; a.refine_pivots = 2;
   if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);
   if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) a.refine_kcap = std::atof(e);
+  if (const char* e = std::getenv("NNSDP_REFINE_PIVOTS")) a.refine_pivots = std::atoi(e);
   struct Events {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }

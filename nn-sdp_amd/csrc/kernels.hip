@@ -36,8 +36,15 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   __syncthreads();
   if (lane == 0) scratch[wv] = v;
   __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+  if ((nw & (nw - 1)) == 0) {
+    // one LDS read and log2(nw) butterfly steps (every lane ends with the same bits: the additions commute) instead of nw dependent
+    // LDS reads - the serial form cost ~3 000 cycles per call with 16 waves, and the projection kernel makes a dozen of them
+    double s = scratch[lane & (nw - 1)];
+    for (int o = nw >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+  }
   double s = 0.0;
-  int nw = (blockDim.x + 63) >> 6;
   for (int i = 0; i < nw; ++i) s += scratch[i];
   return s;
 }
@@ -71,6 +78,7 @@ struct ProjArgs {
   int* rstate;            // refinement back-off per block: (level << 8) | iterations still to skip (may be null)
   double refine_acc;      // a refinement step is accepted without a check when its PREDICTED off(A) is below refine_acc x tol |A|
   double refine_kcap;     // pairs whose first-order rotation angle B_ij / (d_j - d_i) exceeds this are left to the sweeps
+  int refine_pivots;      // exact rotations of the dominant pair first order cannot resolve, per visit (0 = off)
   double refine_loose;    // >= 1: the one-off acceptance level of an isolated near miss, as a multiple of refine_acc (1 = off)
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
@@ -254,6 +262,11 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 
 #ifdef NNSDP_STAMPS
   long long sec_t[6]; sec_t[0] = clock64();
+  long long rst[20];
+  for (int i_ = 0; i_ < 20; ++i_) rst[i_] = 0;
+#define RST(i) { rst[i] = clock64(); }
+#else
+#define RST(i)
 #endif
   // ---- load: A = sym(nu_k) (full, both triangles, for the warm-start products), padded row/col zero; starting basis
   double fro2 = 0.0;
@@ -549,36 +562,6 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   // ceil(half * ceil(nv/32) / VG) for the sizes each variant is launched with (n <= 96 when V is in LDS)
   constexpr int MAXU = PK ? 15 : (NT == 1024) ? (V_LDS ? 5 : 9) : 7;   // V in HBM: blocks up to n = 128 (160 packed: 80 x 5 units over 28 groups)
   constexpr int VG = (NT - kParamLanes) / 32;
-  int blk[MAXB];
-  {
-    const int R = (half + 1) >> 1, Wd = half + 1;
-#pragma unroll
-    for (int u = 0; u < MAXB; ++u) {
-      int b = tid + u * NT;
-      int v = -1;
-      if (b < R * Wd) {
-        int row = b / Wd, m = b - row * Wd;
-        int iahi = half - 1 - row;
-        if (m <= row) v = (row << 8) | m;
-        else if (iahi != row) v = (iahi << 8) | (m - row - 1);
-      }
-      blk[u] = v;
-    }
-  }
-  const int nch = (nv + 31) >> 5;
-  const int vr = tid & 31, vg = tid >> 5;
-  int vunit[MAXU];
-#pragma unroll
-  for (int u = 0; u < MAXU; ++u) {
-    int un = vg + u * VG;
-    int v = -1;
-    if (plane < 0 && un < half * nch) {
-      int ia = un / nch, ch = un - ia * nch;
-      int row = ch * 32 + vr;
-      if (row < nv) v = (ia << 8) | row;
-    }
-    vunit[u] = v;
-  }
 #ifdef NNSDP_STAMPS
   long long st_acc[4] = {0, 0, 0, 0};
 #define STAMP(i, tprev) { long long tn_ = clock64(); st_acc[i] += tn_ - tprev; tprev = tn_; }
@@ -715,14 +698,29 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
                 }
               }
             }
-        off2 = uniform(block_sum(o2, red));
-        k2 = uniform(block_sum(q2, red));
-        unpp = uniform(block_sum(upp, red));
-        unnn = uniform(block_sum(unn, red));
-        unx = uniform(block_sum(ux, red));
-        kd2 = uniform(block_sum(qd2, red));
-        cpos = uniform(block_sum((tid < n && dvec[tid] > 0.0) ? 1.0 : 0.0, red));
-        cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
+        // the six sums in ONE reduction (two barriers instead of sixteen): wave sums into rsc[q * 16 + wave] (96 doubles behind this
+        // block's V: the V region is a bordered matrix of (npg + 2) x 100 doubles for the sweeps, V itself takes npg x 99 of them),
+        // 16-lane butterflies over the waves, totals into red[0..5] (free after the first barrier: every wave is through gram_diag's reduction by then); the sign counts by
+        // ballot into rsc[96..99]
+        double* const rsc = V + (size_t)npg * ldv;
+        static_assert(NW == 16, "the refinement stage's reductions assume 16 waves");
+        o2 = wave_sum(o2); q2 = wave_sum(q2); upp = wave_sum(upp); unn = wave_sum(unn); ux = wave_sum(ux); qd2 = wave_sum(qd2);
+        if (lane == 0) { rsc[wv] = o2; rsc[16 + wv] = q2; rsc[32 + wv] = upp; rsc[48 + wv] = unn; rsc[64 + wv] = ux; rsc[80 + wv] = qd2; }
+        if (tid < 128) {
+          const double dv = tid < n ? dvec[tid] : 0.0;
+          const unsigned long long bp = __ballot(dv > 0.0), bn = __ballot(dv < 0.0);
+          if (lane == 0) { rsc[96 + 2 * wv] = (double)__popcll(bp); rsc[97 + 2 * wv] = (double)__popcll(bn); }
+        }
+        __syncthreads();
+        if (tid < 96) {
+          double v = rsc[tid];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          if ((tid & 15) == 0) red[tid >> 4] = v;
+        }
+        __syncthreads();
+        off2 = uniform(red[0]); k2 = uniform(red[1]); unpp = uniform(red[2]); unnn = uniform(red[3]); unx = uniform(red[4]); kd2 = uniform(red[5]);
+        cpos = uniform(rsc[96] + rsc[98]); cneg = uniform(rsc[97] + rsc[99]);
         __syncthreads();      // (the reduction scratch is free again: the paths that follow reuse it without another barrier)
       };
       // the step: X = E~ + E~^2 / 2 over B (both triangles and the diagonal), V <- V (I + X); with_sums: column sums of E~^2 and
@@ -747,6 +745,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
               } else if (i == j) A[i * lda + i] = 0.5 * rdg[i];
             }
         __syncthreads();
+        RST(4)
         if (with_sums) {
           const int col = tid >> 3, part = tid & 7;     // 8 lanes per column
           double s1 = 0.0, s2 = 0.0;
@@ -757,6 +756,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 8); s2 += __shfl_xor(s2, o, 8); }
           if (part == 0 && col < npg) { cs1[col] = s1; cs2[col] = s2; }
         }
+        RST(5)
         // second-order term of the rotation: X = E~ + E~^2 / 2 ~ exp(K) - I, so that V (I + X) is orthogonal to THIRD order - with
         // the first-order step alone the projection carries an error |K^2 D| that no later iteration takes back.  E~^2 is symmetric
         // (E~ is antisymmetric up to R): lower tiles on the matrix cores, added to both triangles
@@ -784,7 +784,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
               }
             }
         __syncthreads();
+        RST(6)
         v_update();
+        RST(7)
       };
       // B = V'AV again from the matrix in HBM (the A buffer held X)
       auto rebuild_B = [&]() {
@@ -804,31 +806,101 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       // CHECKED: B is rebuilt with the new basis (round 1) and accepted when its measured off(B) is inside the accepted level - a
       // third of the price of a sweep.  Whatever is left goes on to the exact sweeps from a valid (B, V).
       int outcome = 2;      // 0: converged as it arrived, 1: one step (unchecked), 2: on to the sweeps, 3: step + check
+      RST(0)
+      bool check = false, far = true, loose = false;      // far: the prediction missed by more than 10 x (the iterate still moves fast)
+      double pred0 = 0.0;
+      auto decide = [&]() {
+        if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
+        else if (r2 <= 1e-4) {
+          pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
+          const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);    // rebuilding from the positive / negative side
+          const bool prefer_pos = cpos <= cneg;
+          const bool kok = k2 <= 0.09;      // |K|_F <= 0.3: the step is a rotation to |K|^3 / 6 < 5e-3 whatever the eigenvalues it touches
+          if (kok && (prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
+          else if (kok && (prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
+          // an isolated near miss: a block that took the step at the regular level on its last 16 visits may take ONE step whose prediction
+          // is up to refine_loose x higher (the prediction is an upper bound: the error itself is 0.06 x it at the median) instead of
+          // holding the whole launch up for a sweep
+          else if (kok && credit >= 16 && fmin(pred_pos, pred_neg) <= a.refine_loose * accT) { side_force = pred_pos <= pred_neg ? 1 : -1; loose = true; }
+          // (the checked form needs a step that is a rotation at all: |K|_F <= 0.3 keeps V (I + X) orthogonal to |K|^3 / 6 < 5e-3,
+          // which the Newton-Schulz repair below takes back if the check then fails)
+          else check = rmode >= 2 && k2 <= 0.09 && fmin(pred_pos, pred_neg) <= 30.0 * accT;
+          far = fmin(pred_pos, pred_neg) > 10.0 * accT;
+        }
+      };
       gram();
+      RST(1)
       if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
       r2 = uniform(gram_diag());           // (two barriers inside: dvec / rdg are visible afterwards)
+      RST(2)
       analyse();
-      bool check = false, far = true, loose = false;      // far: the prediction missed by more than 10 x (the iterate still moves fast)
-      if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
-      else if (r2 <= 1e-4) {
-        const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
-        const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);    // rebuilding from the positive / negative side
-        const bool prefer_pos = cpos <= cneg;
-        const bool kok = k2 <= 0.09;      // |K|_F <= 0.3: the step is a rotation to |K|^3 / 6 < 5e-3 whatever the eigenvalues it touches
-        if (kok && (prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
-        else if (kok && (prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
-        // an isolated near miss: a block that took the step at the regular level on its last 16 visits may take ONE step whose prediction
-        // is up to refine_loose x higher (the prediction is an upper bound: the error itself is 0.06 x it at the median) instead of
-        // holding the whole launch up for a sweep
-        else if (kok && credit >= 16 && fmin(pred_pos, pred_neg) <= a.refine_loose * accT) { side_force = pred_pos <= pred_neg ? 1 : -1; loose = true; }
-        // (the checked form needs a step that is a rotation at all: |K|_F <= 0.3 keeps V (I + X) orthogonal to |K|^3 / 6 < 5e-3,
-        // which the Newton-Schulz repair below takes back if the check then fails)
-        else check = rmode >= 2 && k2 <= 0.09 && fmin(pred_pos, pred_neg) <= 30.0 * accT;
-        far = fmin(pred_pos, pred_neg) > 10.0 * accT;
-        if (side_force == 0 && tid == 0 && a.stats) {      // diagnostic: which term of the prediction rejected the block
-          const double ua = sqrt(unx), ub = sqrt(fmin(unpp, unnn));
-          atomicAdd(&a.stats[pred0 >= ua && pred0 >= ub ? 9 : (ua >= ub ? 10 : 11)], 1);
+      decide();
+      RST(3)
+      // What first order cannot resolve late in a solve is almost always ONE pair of eigenvalues on either side of zero (two thirds of
+      // the rejections of W40-D20 after iteration 12 000): when the rest of the prediction passes, rotate that pair exactly - two columns
+      // of V, the pair's rows of B (lower triangle: the strict upper tiles still hold the first product of the congruence); B and V
+      // stay consistent - and look again (at most refine_pivots times; Gram product and analysis only).
+      int pivots = 0;
+      if (__builtin_expect(!refined && side_force == 0 && r2 <= 1e-4 && k2 <= 0.09 && unx > 0.0 && a.refine_pivots > 0, 0)) {
+        for (;;) {
+          // the largest coupling that counts against both sides
+          double pm = 0.0;
+          int pidx = 0;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            if (tti[m] >= 0)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+                if (i > j && i < n) {
+                  const double b = A[i * lda + j];
+                  const double li = dvec[i] * (1.0 + rdg[i]), lj = dvec[j] * (1.0 + rdg[j]);
+                  const double gap = lj - li;
+                  if (!(fabs(b) <= kcap * fabs(gap) && gap != 0.0) && !(b * b < dvec[i] * dvec[j]) && b * b > pm) { pm = b * b; pidx = (i << 8) | j; }
+                }
+              }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(pm, o, 64);
+            const int oi = __shfl_xor(pidx, o, 64);
+            if (om > pm || (om == pm && oi > pidx)) { pm = om; pidx = oi; }
+          }
+          if (lane == 0) { cs1[wv] = pm; cs2[wv] = (double)pidx; }
+          __syncthreads();
+          pm = 0.0; pidx = 0;
+          for (int w_ = 0; w_ < NW; ++w_) { const double om = cs1[w_]; const int oi = (int)cs2[w_]; if (om > pm || (om == pm && oi > pidx)) { pm = om; pidx = oi; } }
+          pm = uniform(pm); pidx = __builtin_amdgcn_readfirstlane(pidx);
+          if (!(pm > 0.0) || !(pred0 + sqrt(fmax(fmin(unpp, unnn) + unx - 2.0 * pm, 0.0)) <= accT)) break;     // (uniform)
+          const int p_ = pidx >> 8, q_ = pidx & 255;       // p_ > q_
+          const double bpp = A[p_ * lda + p_], bqq = A[q_ * lda + q_], bpq = A[p_ * lda + q_];
+          const double tau = (bqq - bpp) / (2.0 * bpq);
+          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double cc = 1.0 / sqrt(1.0 + tt * tt), ss = tt * cc;
+          __syncthreads();
+          if (tid < n) {
+            // B <- J'BJ, J = [c s; -s c] in the (p, q) plane: entries (k, p), (k, q) of the lower triangle, and the 2 x 2 block
+            if (tid != p_ && tid != q_) {
+              double* xp = tid > p_ ? A + tid * lda + p_ : A + p_ * lda + tid;
+              double* xq = tid > q_ ? A + tid * lda + q_ : A + q_ * lda + tid;
+              const double x = *xp, y = *xq; *xp = cc * x - ss * y; *xq = ss * x + cc * y;
+            } else if (tid == p_) { A[p_ * lda + p_] = bpp - tt * bpq; A[q_ * lda + q_] = bqq + tt * bpq; A[p_ * lda + q_] = 0.0; }
+          } else if (tid >= 128 && tid < 128 + n) {
+            double* vp = V + (tid - 128) + (size_t)p_ * ldv; double* vq = V + (tid - 128) + (size_t)q_ * ldv;
+            const double x = *vp, y = *vq; *vp = cc * x - ss * y; *vq = ss * x + cc * y;
+          }
+          __syncthreads();
+          ++pivots;
+          gram();
+          if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
+          r2 = uniform(gram_diag());
+          analyse();
+          decide();
+          if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= 0.09) || !(unx > 0.0)) break;
         }
+      }
+      if (side_force == 0 && !refined && r2 <= 1e-4 && tid == 0 && a.stats) {      // diagnostic: which term of the prediction rejected the block
+        const double ua = sqrt(unx), ub = sqrt(fmin(unpp, unnn));
+        atomicAdd(&a.stats[pred0 >= ua && pred0 >= ub ? 9 : (ua >= ub ? 10 : 11)], 1);
       }
       if (side_force != 0) {
         step(true);
@@ -846,6 +918,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           }
         }
         __syncthreads();
+        RST(8)
         outcome = 1;
         refined = true;
       } else if (check) {
@@ -903,7 +976,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
       }
       if (tid == 0) {
-        if (a.stats) atomicAdd(&a.stats[outcome == 3 || loose ? 8 : 4 + outcome], 1);
+        if (a.stats) { atomicAdd(&a.stats[outcome == 3 || loose ? 8 : 4 + outcome], 1); if (pivots) atomicAdd(&a.stats[outcome == 1 ? 12 : 13], pivots); }
         if (a.rstate) {
           // back-off: a block whose prediction misses by more than 10 x TWICE IN A ROW skips the attempt for 2, 4, 8, 16 iterations (the
           // Gram product and the analysis are wasted work while the iterate still moves fast); near misses - the isolated failures
@@ -917,6 +990,37 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       a.rstate[k] = (credit << 16) | (level << 8) | (wait - 1);
       if (a.stats) atomicAdd(&a.stats[7], 1);
     }
+  }
+  // (the sweeps' static work assignment is computed after the refinement stage: nothing of it is live across the stage)
+  int blk[MAXB];
+  {
+    const int R = (half + 1) >> 1, Wd = half + 1;
+#pragma unroll
+    for (int u = 0; u < MAXB; ++u) {
+      int b = tid + u * NT;
+      int v = -1;
+      if (b < R * Wd) {
+        int row = b / Wd, m = b - row * Wd;
+        int iahi = half - 1 - row;
+        if (m <= row) v = (row << 8) | m;
+        else if (iahi != row) v = (iahi << 8) | (m - row - 1);
+      }
+      blk[u] = v;
+    }
+  }
+  const int nch = (nv + 31) >> 5;
+  const int vr = tid & 31, vg = tid >> 5;
+  int vunit[MAXU];
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    int un = vg + u * VG;
+    int v = -1;
+    if (plane < 0 && un < half * nch) {
+      int ia = un / nch, ch = un - ia * nch;
+      int row = ch * 32 + vr;
+      if (row < nv) v = (ia << 8) | row;
+    }
+    vunit[u] = v;
   }
   if (refined) {
     // eigenvalues on the diagonal of A, eigenvectors in V: nothing left to do before the reconstruction
@@ -1602,8 +1706,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     if (tid == 0) { dbg[64] = sweeps; dbg[65] = sec_t[1] - sec_t[0]; dbg[66] = sec_t[2] - sec_t[1]; dbg[67] = sec_t[3] - sec_t[2]; dbg[68] = sec_t[3]; }
   }
 #endif
-  if (tid == 0 && a.stats) { atomicAdd(&a.stats[0], sweeps); atomicMax(&a.stats[1], sweeps); }
-  if (a.stats && plane >= 0 && plane < half) { atomicAdd(&a.stats[2], nrot); atomicAdd(&a.stats[3], sweeps * M); }
+  if (tid == 0 && a.stats && sweeps > 0) { atomicAdd(&a.stats[0], sweeps); atomicMax(&a.stats[1], sweeps); }
+  if (a.stats && sweeps > 0 && plane >= 0 && plane < half) { atomicAdd(&a.stats[2], nrot); atomicAdd(&a.stats[3], sweeps * M); }
 
   // ---- eigenvalues on the diagonal; the smaller side of the spectrum gives the rank-k update
   {
@@ -1633,6 +1737,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     if (tid == 0) { sel[npg] = up ? npos : nneg; sel[npg + 1] = up ? 1 : 0; }
   }
   __syncthreads();
+  RST(10)
   const int nsel = sel[npg];
   const bool use_pos = sel[npg + 1] != 0;
   if (a.eig && tid < n) a.eig[a.eoff[k] + tid] = A[ixl(tid + pofs, tid + pofs)];
@@ -1685,6 +1790,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         wk[(size_t)j * n + i] = s;
       }
   }
+  RST(11)
   if (kap != 1.0) {
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += NT) { double wv = wk[idx]; nuw[idx] = wv + kap * (nuw[idx] - wv); }
@@ -1696,6 +1802,12 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   }
 #ifdef NNSDP_STAMPS
   if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
+  if (PP && k == 0 && (tid == 0 || tid == NT - 64) && !a.eig) {
+    const long long te = clock64();
+    printf("[stamps n=%d wave %d] load %lld congruence %lld to-stage %lld | gram %lld diag %lld analyse %lld | E~ %lld sums %lld E~^2 %lld V-update %lld lambda %lld | to-select %lld select %lld W %lld V-store %lld | total %lld\n",
+           n, tid >> 6, sec_t[1] - sec_t[0], sec_t[2] - sec_t[1], rst[0] - sec_t[2], rst[1] - rst[0], rst[2] - rst[1], rst[3] - rst[2], rst[4] - rst[3], rst[5] - rst[4],
+           rst[6] - rst[5], rst[7] - rst[6], rst[8] - rst[7], sec_t[3] - (rst[8] ? rst[8] : rst[3]), rst[10] - sec_t[3], rst[11] - rst[10], te - rst[11], te - sec_t[0]);
+  }
 #endif
 }
 

@@ -115,6 +115,36 @@ def test_refinement_edge_cases_fall_back_to_exact_sweeps(case):
         assert oc[0] == 1, oc
 
 
+@pytest.mark.parametrize("n", [57, 85])
+def test_one_unresolvable_pair_across_zero_is_rotated_exactly(n, monkeypatch):
+    """the late-solve rejection: ONE pair of eigenvalues on either side of zero whose coupling is far above their gap (first order cannot
+    resolve it, and it counts whichever side the projection is rebuilt from).  The stage rotates that pair exactly and takes its step;
+    without the rotation (NNSDP_REFINE_PIVOTS=0) the same input goes on to the sweeps.  Both within their bounds of LAPACK."""
+    rng = np.random.default_rng(n)
+    h = n // 2
+    spec = np.concatenate([np.linspace(0.2, 2.0, h - 1), [1e-4, -1e-4], -np.linspace(0.1, 1.5, n - h - 1)])
+    Q0, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    E = 1e-7 * rng.standard_normal((n, n))
+    E = 0.5 * (E + E.T)
+    E[h - 1, h] = E[h, h - 1] = 1e-3
+    A1 = Q0 @ (np.diag(spec) + E) @ Q0.T
+    A1 = 0.5 * (A1 + A1.T)
+    tol = 1e-7
+    assert 1e-3 > 30 * tol * np.linalg.norm(A1)            # the coupling alone is above the level a step may leave behind
+    Wx = oadmm.project_psd(A1)
+    W, V, oc, _ = na.project_psd_warm([A1], [Q0], tol, refine=True)
+    assert oc[1] == 1, oc
+    assert np.linalg.norm(W[0] - Wx) <= 30 * tol * np.linalg.norm(A1)
+    assert np.linalg.norm(V[0].T @ V[0] - np.eye(n)) <= 1e-6
+    # the basis it returns diagonalises the matrix: a second visit finds the block converged (nothing left of the pair)
+    W2, V2, oc2, _ = na.project_psd_warm([A1], [V[0]], 30 * tol, refine=True)
+    assert oc2[0] == 1, oc2
+    monkeypatch.setenv("NNSDP_REFINE_PIVOTS", "0")
+    W0, V0, oc0, _ = na.project_psd_warm([A1], [Q0], tol, refine=True)
+    assert oc0[2] == 1, oc0
+    assert np.linalg.norm(W0[0] - Wx) <= tol * np.linalg.norm(A1)
+
+
 def test_solver_with_and_without_refinement_agree():
     """a whole solve: same optimum, the refinement stage carries most block visits late in the solve"""
     q = helpers.product_query(helpers.load_problem("W40-D20", 0))
