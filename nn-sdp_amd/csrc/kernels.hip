@@ -23,10 +23,33 @@ static constexpr double kInvSqrt2 = 0.70710678118654752440;
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// lane permutation inside a row of 16 lanes on the VALU (DPP): no LDS traffic, unlike __shfl_* (ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// sums over aligned groups of 8 / 16 lanes (every lane of the group gets the group's sum)
+__device__ __forceinline__ double row_sum8(double v) { v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v); v += dpp_row<0x141>(v); return v; }
+__device__ __forceinline__ double row_sum16(double v) { v = row_sum8(v); v += dpp_row<0x140>(v); return v; }
+
+// sum over the 64 lanes of a (fully active) wave, the same bits in every lane.  Four DPP butterflies give every lane its row's sum
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: the two operands of every addition are swapped between partner
+// lanes, and addition commutes), the four row sums are read as scalars.  The __shfl_down form took 12 ds_bpermute per value: with
+// 16 waves reducing half a dozen values each, the CU's LDS pipe was the bottleneck of the refinement stage's analysis.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_row<0xB1>(v);
+  v += dpp_row<0x4E>(v);
+  v += dpp_row<0x141>(v);
+  v += dpp_row<0x140>(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // block-wide sum, result valid in every thread; scratch >= blockDim/64 doubles of LDS
@@ -40,9 +63,12 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   if ((nw & (nw - 1)) == 0) {
     // one LDS read and log2(nw) butterfly steps (every lane ends with the same bits: the additions commute) instead of nw dependent
     // LDS reads - the serial form cost ~3 000 cycles per call with 16 waves, and the projection kernel makes a dozen of them
-    double s = scratch[lane & (nw - 1)];
-    for (int o = nw >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    return s;
+    const double s = scratch[lane & (nw - 1)];
+    if (nw == 16) return row_sum16(s);
+    if (nw == 8) return row_sum8(s);
+    double t = s;
+    for (int o = nw >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
   }
   double s = 0.0;
   for (int i = 0; i < nw; ++i) s += scratch[i];
@@ -294,7 +320,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         const int j = wvi + 16 * jj, i = ln + 64 * ii;
         if (i < npg && j < npg) { A[i * lda + j] = ta[jj][ii]; V[i + j * ldv] = tv[jj][ii]; }
       }
+    RST(12)
     __syncthreads();
+    RST(13)
     for (int j = wvi; j < n; j += NT >> 6)
       for (int i = ln + j + 1; i < n; i += 64) {
         const double v = 0.5 * (A[i * lda + j] + A[j * lda + i]);
@@ -302,6 +330,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         fro2 += 2.0 * v * v;
       }
     if (tid < n) { const double v = A[tid * lda + tid]; fro2 += v * v; }
+    RST(14)
     fro2 = block_sum(fro2, red);
   } else {
   if constexpr (PK) {
@@ -713,9 +742,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
         __syncthreads();
         if (tid < 96) {
-          double v = rsc[tid];
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          const double v = row_sum16(rsc[tid]);
           if ((tid & 15) == 0) red[tid >> 4] = v;
         }
         __syncthreads();
@@ -752,8 +779,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           if (col < n)
             for (int kx = part; kx < n; kx += 8)
               if (kx != col) { const double e = A[kx * lda + col]; s1 += e * e; s2 += e * e * dvec[kx]; }
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 8); s2 += __shfl_xor(s2, o, 8); }
+          s1 = row_sum8(s1); s2 = row_sum8(s2);
           if (part == 0 && col < npg) { cs1[col] = s1; cs2[col] = s2; }
         }
         RST(5)
@@ -909,8 +935,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           double nr = 0.0;
           if (col < n)
             for (int rx = part; rx < n; rx += 8) { const double v = V[rx + (size_t)col * ldv]; nr += v * v; }
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) nr += __shfl_xor(nr, o, 8);
+          nr = row_sum8(nr);
           if (part == 0 && col < npg) {
             double lamn = 0.0;
             if (col < n) { const double d = dvec[col]; lamn = (d * (1.0 + rdg[col] + cs1[col]) - cs2[col]) / nr; }
@@ -1804,8 +1829,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
   if (PP && k == 0 && (tid == 0 || tid == NT - 64) && !a.eig) {
     const long long te = clock64();
-    printf("[stamps n=%d wave %d] load %lld congruence %lld to-stage %lld | gram %lld diag %lld analyse %lld | E~ %lld sums %lld E~^2 %lld V-update %lld lambda %lld | to-select %lld select %lld W %lld V-store %lld | total %lld\n",
-           n, tid >> 6, sec_t[1] - sec_t[0], sec_t[2] - sec_t[1], rst[0] - sec_t[2], rst[1] - rst[0], rst[2] - rst[1], rst[3] - rst[2], rst[4] - rst[3], rst[5] - rst[4],
+    printf("[stamps n=%d wave %d] (load: to LDS %lld barrier %lld symmetrise %lld sum %lld) load %lld congruence %lld to-stage %lld | gram %lld diag %lld analyse %lld | E~ %lld sums %lld E~^2 %lld V-update %lld lambda %lld | to-select %lld select %lld W %lld V-store %lld | total %lld\n",
+           n, tid >> 6, rst[12] - sec_t[0], rst[13] - rst[12], rst[14] - rst[13], sec_t[1] - rst[14], sec_t[1] - sec_t[0], sec_t[2] - sec_t[1], rst[0] - sec_t[2], rst[1] - rst[0], rst[2] - rst[1], rst[3] - rst[2], rst[4] - rst[3], rst[5] - rst[4],
            rst[6] - rst[5], rst[7] - rst[6], rst[8] - rst[7], sec_t[3] - (rst[8] ? rst[8] : rst[3]), rst[10] - sec_t[3], rst[11] - rst[10], te - rst[11], te - sec_t[0]);
   }
 #endif
