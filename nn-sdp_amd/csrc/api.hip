@@ -448,7 +448,7 @@ struct nnsdp_solver {
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
     d_stats.alloc(14); d_stats.zero();
-    d_rstate.alloc(std::max(ncl, 1)); d_rstate.zero();
+    d_rstate.alloc(4 * (size_t)std::max(ncl, 1)); d_rstate.zero();      // (4 ints per block: kernels.hip, ProjArgs::rstate)
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
     if (const char* e = std::getenv("NNSDP_REFINE_ACC")) refine_acc = std::atof(e);
     if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) refine_kcap = std::atof(e);
@@ -756,7 +756,7 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    a.refine = opt.proj_refine; a.rstate = d_rstate.p + k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_pivots = refine_pivots;
+    a.refine = opt.proj_refine; a.rstate = d_rstate.p + 4 * k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_pivots = refine_pivots;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
@@ -1959,7 +1959,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV, dT;
   dcn.upload(cn); dco.upload(coff);
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dT.alloc(tot);
-  dst.alloc(14); dst.zero(); drs.alloc(batch); drs.zero();
+  dst.alloc(14); dst.zero(); drs.alloc(4 * (size_t)batch); drs.zero();
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
   const int alg = proj_algorithm(nmax);

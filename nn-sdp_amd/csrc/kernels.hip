@@ -101,7 +101,8 @@ struct ProjArgs {
   int warm;               // 1: use Vg as the starting basis
   int refine;             // 1: warm blocks first try the GEMM-only refinement of the persistent basis (ping-pong variant only);
                           // 2: also the checked form (step, rebuild B, measure) for blocks whose prediction fails by less than 30 x
-  int* rstate;            // refinement back-off per block: (level << 8) | iterations still to skip (may be null)
+  int* rstate;            // refinement state per block, 4 ints: [0] = (Gram credit << 24) | (success credit << 16) | (back-off level << 8) |
+                          // iterations still to skip, [2..3] = estimate of |I - V'V|_F as a double; zero-initialised (may be null)
   double refine_acc;      // a refinement step is accepted without a check when its PREDICTED off(A) is below refine_acc x tol |A|
   double refine_kcap;     // pairs whose first-order rotation angle B_ij / (d_j - d_i) exceeds this are left to the sweeps
   int refine_pivots;      // exact rotations of the dominant pair first order cannot resolve, per visit (0 = off)
@@ -612,8 +613,12 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   bool refined = false;
   int side_force = 0;     // refinement step accepted for ONE side of the spectrum: the reconstruction must use it (+1 positive, -1 negative)
   if constexpr (PP) {
-    int wait = 0, level = 0, credit = 0;
-    if (a.rstate) { const int rs = a.rstate[k]; wait = rs & 255; level = (rs >> 8) & 255; credit = (rs >> 16) & 255; }
+    int wait = 0, level = 0, credit = 0, gcred = 0;
+    double rdef = 0.0;      // estimate (upper bound) of the basis' defect |I - V'V|_F since it was last measured
+    if (a.rstate) {
+      const int rs = a.rstate[4 * k]; wait = rs & 255; level = (rs >> 8) & 255; credit = (rs >> 16) & 255; gcred = (rs >> 24) & 15;
+      rdef = *reinterpret_cast<const double*>(a.rstate + 4 * k + 2);
+    }
     // EVERY wave must have read the block's back-off state before thread 0 rewrites it (the skip branch below does so at once): a
     // wave that loaded the word after that store saw wait - 1, entered the stage and its barriers while the others skipped it - a
     // barrier mismatch that showed only when three processes shared the card (the two-rank tests: one solve in five diverged)
@@ -719,7 +724,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
                   const double e = (b + lj * rr) * rcp_nr2(gap), f = rr - e;
                   q2 += e * e + f * f;
                   qd2 += e * e * lj * lj + f * f * li * li;
+                  A[j * lda + i] = e;            // kept for the step in the mirror position (nothing reads the upper triangle of B)
                 } else {
+                  A[j * lda + i] = __longlong_as_double(0x7ff8000000000000LL);      // "not resolved"
                   q2 += 0.5 * rr * rr;
                   const double dd = dvec[i] * dvec[j];
                   if (b * b < dd) { if (dvec[i] > 0.0) upp += 2.0 * b * b; else unn += 2.0 * b * b; }   // same sign, inertia kept
@@ -762,10 +769,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
               if (i > j) {
                 double e = 0.0, f = 0.0;
                 if (i < n) {
-                  const double b = A[i * lda + j], rr = -g[m][r];
-                  const double li = dvec[i] * (1.0 + rdg[i]), lj = dvec[j] * (1.0 + rdg[j]);
-                  const double gap = lj - li;
-                  if (fabs(b) <= kcap * fabs(gap) && gap != 0.0) { e = (b + lj * rr) * rcp_nr2(gap); f = rr - e; }
+                  const double rr = -g[m][r];
+                  e = A[j * lda + i];            // from the analysis: E~_ij of a resolved pair, NaN otherwise
+                  if (e == e) f = rr - e;
                   else { e = 0.5 * rr; f = e; }
                 }
                 A[i * lda + j] = e; A[j * lda + i] = f;
@@ -854,10 +860,23 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           far = fmin(pred_pos, pred_neg) > 10.0 * accT;
         }
       };
-      gram();
-      RST(1)
-      if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
-      r2 = uniform(gram_diag());           // (two barriers inside: dvec / rdg are visible afterwards)
+      // The Gram product is not taken on every visit: a step with an antisymmetric K leaves (I + K + K^2 / 2)'(I + K + K^2 / 2) =
+      // I + K^4 / 4, so the defect of V grows by |K|_F^4 / 4 per step at most - the estimate rdef carries that bound from the last
+      // measurement, three visits in four run with R = 0 (no re-orthogonalisation term, a fifth of the stage's matrix work saved),
+      // and any visit whose estimate comes near the accepted error level measures again.  Zero-initialised state measures first.
+      const bool do_gram = !a.rstate || gcred == 0 || !(rdef <= 0.03 * a.refine_acc * tolv);
+      bool measured = do_gram;
+      if (do_gram) {
+        gram();
+        RST(1)
+        if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
+        r2 = uniform(gram_diag());           // (two barriers inside: dvec / rdg are visible afterwards)
+      } else {
+        g[0] = d4_t{0.0, 0.0, 0.0, 0.0}; g[1] = d4_t{0.0, 0.0, 0.0, 0.0};
+        if (tid < npg) { dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0; rdg[tid] = 0.0; }
+        r2 = rdef * rdef;
+        __syncthreads();
+      }
       RST(2)
       analyse();
       decide();
@@ -916,9 +935,14 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           }
           __syncthreads();
           ++pivots;
-          gram();
-          if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
-          r2 = uniform(gram_diag());
+          if (do_gram) {      // (a plane rotation leaves R = I - V'V rotated, its norm unchanged)
+            gram();
+            if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
+            r2 = uniform(gram_diag());
+          } else {
+            if (tid < npg) dvec[tid] = tid < n ? A[tid * lda + tid] : 0.0;
+            __syncthreads();
+          }
           analyse();
           decide();
           if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= 0.09) || !(unx > 0.0)) break;
@@ -953,6 +977,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         rebuild_B();
         gram();
         r2 = uniform(gram_diag());
+        measured = true;
         double o2 = 0.0;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -977,6 +1002,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
               V[i + (size_t)j * ldv] = (i == j) ? 1.0 : 0.0;
             }
           __syncthreads();
+          r2 = 0.0; measured = true;
         } else if (r2 > a.refine_acc * a.refine_acc * tolv * tolv) {
           // on to the sweeps, which keep V only as orthogonal as they find it: a defect above the error level accepted for refinement
           // steps is first put right by Newton-Schulz steps V <- V (I + R / 2) (R -> 3/8 R^2 each), then B is rebuilt.  (A smaller
@@ -1006,13 +1032,20 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           // back-off: a block whose prediction misses by more than 10 x TWICE IN A ROW skips the attempt for 2, 4, 8, 16 iterations (the
           // Gram product and the analysis are wasted work while the iterate still moves fast); near misses - the isolated failures
           // late in a solve - try again at once; a success resets the level
-          if (outcome == 2 && far) { const int lv = min(level + 1, 5); a.rstate[k] = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }
-          else if (outcome == 2) a.rstate[k] = (credit << 16) | (level << 8);
-          else a.rstate[k] = loose ? 0 : (min(credit + 1, 255) << 16);
+          int word;
+          if (outcome == 2 && far) { const int lv = min(level + 1, 5); word = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }
+          else if (outcome == 2) word = (credit << 16) | (level << 8);
+          else word = loose ? 0 : (min(credit + 1, 255) << 16);
+          // the defect estimate: measured where a Gram product was taken (a step with the R term removes it to second order), otherwise
+          // carried; every step adds its |K|_F^4 / 4
+          double rnew = measured ? sqrt(r2) : rdef;
+          if (outcome == 1) rnew = (do_gram ? r2 + 2.0 * sqrt(r2 * k2) : rdef) + 0.25 * k2 * k2;
+          a.rstate[4 * k] = word | ((do_gram ? 3 : gcred - 1) << 24);
+          *reinterpret_cast<double*>(a.rstate + 4 * k + 2) = rnew;
         }
       }
     } else if (warm && rmode != 0 && wait > 0 && tid == 0) {
-      a.rstate[k] = (credit << 16) | (level << 8) | (wait - 1);
+      a.rstate[4 * k] = (gcred << 24) | (credit << 16) | (level << 8) | (wait - 1);
       if (a.stats) atomicAdd(&a.stats[7], 1);
     }
   }
@@ -1781,6 +1814,14 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
       int tj = t - ti * (ti + 1) / 2;
       d4_t c = {0.0, 0.0, 0.0, 0.0};
+      double sn[4] = {0.0, 0.0, 0.0, 0.0};      // sym(nu) of the tile, requested before the products (L2 latency behind the matrix work)
+      if (!use_pos) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti + lc + 4 * r, col = 16 * tj + lr;
+          if (row < n && col < n) sn[r] = 0.5 * (nuk[(size_t)col * n + row] + nuk[(size_t)row * n + col]);
+        }
+      }
       for (int kk = 0; kk < ks; ++kk) {
         int tt = 4 * kk + lc;
         double av = 0.0, bv = 0.0;
@@ -1796,7 +1837,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         int row = 16 * ti + lc + 4 * r, col = 16 * tj + lr;
         if (row < n && col < n) {
           double v = c[r];
-          if (!use_pos) v = 0.5 * (nuk[(size_t)col * n + row] + nuk[(size_t)row * n + col]) - v;
+          if (!use_pos) v = sn[r] - v;
           wk[(size_t)col * n + row] = v;
           if (ti != tj) wk[(size_t)row * n + col] = v;
         }
