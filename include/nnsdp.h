@@ -260,6 +260,11 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
  * refinement step / sent on to the sweeps / not attempted / accepted after a checked step.  Matrices up to 160.  Host pointers. */
 int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
                            int32_t* outcome, double* kernel_ms);
+/* The same with the refinement stage's per-block state carried between calls, as a solver carries it between iterations: state (in /
+ * out, 4 x batch int32, all zero before the first call; NULL = fresh state every call) holds the back-off word - bits 24..27 of word
+ * 0 count the visits that may still run without the Gram product V'V - and the running estimate of |I - V'V|_F (words 2..3, a double). */
+int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
+                                 int32_t* outcome, double* kernel_ms, int32_t* state);
 
 /* Multi-GPU clique-sharded mode (one SDP over several GPUs of one node): every rank creates the same solver,
  * then nnsdp_solver_set_comm() before the first iteration.  Rank r projects a contiguous range of cliques

@@ -1939,6 +1939,11 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
 
 int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
                            int32_t* outcome, double* kernel_ms) {
+  return nnsdp_project_psd_warm_state(batch, n, mats, basis, tol, refine, out, outcome, kernel_ms, nullptr);
+}
+
+int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* mats, double* basis, double tol, int32_t refine, double* out,
+                                 int32_t* outcome, double* kernel_ms, int32_t* state) {
   API_BEGIN
   if (batch < 0) throw std::invalid_argument("batch must be >= 0");
   if (batch == 0) return 0;
@@ -1960,6 +1965,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   dcn.upload(cn); dco.upload(coff);
   dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dT.alloc(tot);
   dst.alloc(14); dst.zero(); drs.alloc(4 * (size_t)batch); drs.zero();
+  if (state) HIPCHK(hipMemcpy(drs.p, state, 4 * (size_t)batch * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
   const int alg = proj_algorithm(nmax);
@@ -1988,6 +1994,7 @@ int nnsdp_project_psd_warm(int32_t batch, const int32_t* n, const double* mats, 
   if (kernel_ms) *kernel_ms = ms;
   HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(basis, dV.p, tot * sizeof(double), hipMemcpyDeviceToHost));
+  if (state) HIPCHK(hipMemcpy(state, drs.p, 4 * (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
   if (outcome) { std::vector<int> st = dst.download(); for (int i = 0; i < 5; ++i) outcome[i] = st[4 + i]; }
   API_END
 }

@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           // the defect estimate: measured where a Gram product was taken (a step with the R term removes it to second order), otherwise
           // carried; every step adds its |K|_F^4 / 4
           double rnew = measured ? sqrt(r2) : rdef;
-          if (outcome == 1) rnew = (do_gram ? r2 + 2.0 * sqrt(r2 * k2) : rdef) + 0.25 * k2 * k2;
+          if (outcome == 1) rnew = (do_gram ? r2 + 2.0 * sqrt(r2 * k2) : rdef * (1.0 + 2.2 * sqrt(k2))) + 0.25 * k2 * k2;     // ((I + X)'R(I + X) of an uncorrected R)
           a.rstate[4 * k] = word | ((do_gram ? 3 : gcred - 1) << 24);
           *reinterpret_cast<double*>(a.rstate + 4 * k + 2) = rnew;
         }

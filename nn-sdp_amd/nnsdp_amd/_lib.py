@@ -93,6 +93,7 @@ SYMBOLS = [
     ("nnsdp_make_intervals_activ", C.c_int, [C.c_int32, c_int32_p, c_double_p, C.c_int32, c_double_p, c_double_p] + [c_double_p] * 8),
     ("nnsdp_project_psd_batched", C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("nnsdp_project_psd_warm", C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p, c_int32_p, c_double_p]),
+    ("nnsdp_project_psd_warm_state", C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p, c_int32_p, c_double_p, c_int32_p]),
     ("nnsdp_comm_unique_id", C.c_int, [C.c_char_p]),
     ("nnsdp_shard_plan", C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("nnsdp_solver_set_comm", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),

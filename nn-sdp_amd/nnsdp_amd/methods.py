@@ -661,10 +661,12 @@ def project_psd_batched(mats: Sequence[np.ndarray]):
     return res, evs, ms.value
 
 
-def project_psd_warm(mats: Sequence[np.ndarray], bases: Sequence[np.ndarray], tol: float, refine: bool = True):
+def project_psd_warm(mats: Sequence[np.ndarray], bases: Sequence[np.ndarray], tol: float, refine: bool = True, state: Optional[np.ndarray] = None):
     """The projection kernel in its warm form (test entry): bases[b] holds the eigenbasis kept from the previous projection of
     block b (columns = eigenvectors); refine as AdmmSdpOptions.proj_refine (True = 1).  Returns (projections, updated bases, outcome
-    counts [converged, one refinement step, sent on to the sweeps, not attempted, accepted after a checked step], kernel milliseconds)."""
+    counts [converged, one refinement step, sent on to the sweeps, not attempted, accepted after a checked step], kernel milliseconds).
+    state: an int32 array of 4 x len(mats) zeros before the first call, updated in place - the refinement stage's per-block state as
+    a solver carries it from one iteration to the next (nnsdp_project_psd_warm_state)."""
     lib = _lib.load()
     ns = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
     flat = np.concatenate([np.asfortranarray(_f64(m)).ravel(order="F") for m in mats])
@@ -674,9 +676,12 @@ def project_psd_warm(mats: Sequence[np.ndarray], bases: Sequence[np.ndarray], to
     out = np.zeros_like(flat)
     oc = np.zeros(5, dtype=np.int32)
     ms = C.c_double()
-    _lib.check(lib.nnsdp_project_psd_warm(len(mats), ns.ctypes.data_as(_lib.c_int32_p), flat.ctypes.data_as(_lib.c_double_p),
-                                          vb.ctypes.data_as(_lib.c_double_p), float(tol), int(refine), out.ctypes.data_as(_lib.c_double_p),
-                                          oc.ctypes.data_as(_lib.c_int32_p), C.byref(ms)))
+    if state is not None and (state.dtype != np.int32 or state.shape != (4 * len(mats),) or not state.flags.c_contiguous):
+        raise ValueError("state must be a contiguous int32 array of 4 x len(mats)")
+    _lib.check(lib.nnsdp_project_psd_warm_state(len(mats), ns.ctypes.data_as(_lib.c_int32_p), flat.ctypes.data_as(_lib.c_double_p),
+                                                vb.ctypes.data_as(_lib.c_double_p), float(tol), int(refine), out.ctypes.data_as(_lib.c_double_p),
+                                                oc.ctypes.data_as(_lib.c_int32_p), C.byref(ms),
+                                                state.ctypes.data_as(_lib.c_int32_p) if state is not None else None))
     res, vs, o = [], [], 0
     for n in ns:
         res.append(out[o:o + n * n].reshape(n, n, order="F").copy())

@@ -115,6 +115,42 @@ def test_refinement_edge_cases_fall_back_to_exact_sweeps(case):
         assert oc[0] == 1, oc
 
 
+def test_gram_product_is_skipped_three_visits_in_four_and_the_defect_estimate_holds():
+    """with the per-block state carried between calls (as a solver carries it between iterations) the stage measures V'V on one visit
+    in four and runs the others with R = 0; the estimate of |I - V'V|_F it keeps must stay ABOVE the defect numpy measures on the
+    returned basis (it is what decides when to measure again), and the projections must stay inside the promised level"""
+    rng = np.random.default_rng(21)
+    ns = [57, 68, 85]
+    mats, bases = [], []
+    for n in ns:
+        spec = np.concatenate([np.linspace(0.05, 2.0, n - n // 3), -np.linspace(0.05, 1.0, n // 3)])
+        A, Q = _sym(rng, n, spec)
+        mats.append(A)
+        bases.append(Q)
+    eta, tol = 3e-5, 1e-5
+    state = np.zeros(4 * len(ns), dtype=np.int32)
+    credits, steps = [], 0
+    for it in range(24):
+        mats = [_perturb(rng, A, eta) for A in mats]
+        before = state.reshape(-1, 4)[:, 0].copy()
+        W, bases, oc, _ = na.project_psd_warm(mats, bases, tol, refine=True, state=state)
+        steps += oc[1]
+        words = state.reshape(-1, 4)
+        credits.append([(int(w) >> 24) & 15 for w in words[:, 0]])
+        est = words[:, 2:4].copy().view(np.float64).ravel()
+        for k, (A, Wk, Vk) in enumerate(zip(mats, W, bases)):
+            n = len(A)
+            assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * tol * np.linalg.norm(A), (it, k)
+            defect = np.linalg.norm(Vk.T @ Vk - np.eye(n))
+            assert defect <= max(est[k], 1e-13) * 1.01 + 1e-13, (it, k, defect, est[k])
+            assert est[k] <= 0.03 * 30 * tol + 1e-3                       # far below anything that matters; a larger one forces a measurement
+            if ((int(before[k]) >> 24) & 15) > 0 and oc[1] == len(ns):     # a visit that ran on credit used one up
+                assert credits[-1][k] == ((int(before[k]) >> 24) & 15) - 1
+    assert steps >= 60
+    assert credits[0] == [3, 3, 3]                   # the first visit (zero state) measured and granted three visits of credit
+    assert credits[1] == [2, 2, 2] and credits[2] == [1, 1, 1] and credits[3] == [0, 0, 0] and credits[4] == [3, 3, 3]
+
+
 @pytest.mark.parametrize("n", [57, 85])
 def test_one_unresolvable_pair_across_zero_is_rotated_exactly(n, monkeypatch):
     """the late-solve rejection: ONE pair of eigenvalues on either side of zero whose coupling is far above their gap (first order cannot
