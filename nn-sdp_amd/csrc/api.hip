@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -117,13 +118,19 @@ struct FullOperator {
   DevOperator D;
   void build(const nnsdp_problem* p) {
     P.load(p);
+    build_host();
+    upload();
+  }
+  // the two halves apart: the host half (pure host code on this object's own copy of the problem) may run on another thread
+  // while the solver iterates, the upload is the caller's
+  void build_host() {
     Congruence C = make_congruence(P, false);
     pat = build_pattern(P.Zdim, {}, true);
     Operator op = OperatorBuilder(P, C, pat).build();
     S = scale_operator(op, false);
     pat = std::move(op.pat);
-    D.upload(S, pat);
   }
+  void upload() { D.upload(S, pat); }
   // Z (device, Zdim x Zdim column-major) from a full-length gamma (host)
   void assemble(const std::vector<double>& gamma_full, DBuf<double>& Zd, hipStream_t st) {
     std::vector<double> gk(S.ng);
@@ -335,6 +342,9 @@ struct nnsdp_solver {
   double t_setup = 0, t_solve = 0, t_eig = 0, t_create0 = 0;
   double last_pres = 1e300, last_dres = 1e300, last_pobj = 0, last_dobj = 0;
   std::unique_ptr<FullOperator> full;
+  // the certificate's operator (reference coordinates, no normalisation, no cliques) is only needed by finish(): its host half
+  // (13-20 ms at W40-D20) is built on a second thread while the solve runs
+  std::future<std::unique_ptr<FullOperator>> full_fut;
   // clique-sharded mode (one rank per GPU, RCCL all-reduce of the consensus sum per iteration)
   int nranks = 1, rank = 0, k0 = 0, k1 = 0;
   Rccl::Comm comm = nullptr;
@@ -368,7 +378,15 @@ struct nnsdp_solver {
     if (opt.check_every <= 0) opt.check_every = 50;
     if (opt.decomp_mode < NNSDP_DECOMP_DENSE || opt.decomp_mode > NNSDP_DECOMP_PATH)
       throw std::invalid_argument("unrecognized decomp_mode");
+    const bool tm = std::getenv("NNSDP_SETUP_TIMING") != nullptr;     // diagnostic: where the set-up time goes (stderr)
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (tm) { const double t = now_s(); std::fprintf(stderr, "[nnsdp setup] %-28s %7.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
     P.load(prob);
+    if (!std::getenv("NNSDP_NO_ASYNC_SETUP")) {
+      std::unique_ptr<FullOperator> fo(new FullOperator());
+      fo->P = P;
+      full_fut = std::async(std::launch::async, [](std::unique_ptr<FullOperator> f) { f->build_host(); return f; }, std::move(fo));
+    }
     require_gpu();
     if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
     HIPCHK(hipStreamCreate(&st));
@@ -388,8 +406,10 @@ struct nnsdp_solver {
       std::vector<int> layers = P.generator_layers();
       S = scale_operator(op, opt.normalize != 0, &layers);     // multipliers ordered by network layer (any order is the same iteration)
     }
+    lap("operator build (host)");
     pat = std::move(op.pat);
     D.upload(S, pat);
+    lap("operator upload");
     ncl = (int)pat.cliques.size();
     cn.resize(ncl);
     coff.resize(ncl + 1);
@@ -447,6 +467,7 @@ struct nnsdp_solver {
     }
     d_cn.upload(cn); d_coff.upload(coff); d_sptr.upload(sptr); d_soff.upload(soff);
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
+    lap("gather tables + upload");
     d_stats.alloc(14); d_stats.zero();
     d_rstate.alloc(4 * (size_t)std::max(ncl, 1)); d_rstate.zero();      // (4 ints per block: kernels.hip, ProjArgs::rstate)
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
@@ -464,6 +485,7 @@ struct nnsdp_solver {
     // M^-1 on the device (rocSOLVER potrf + potri; one-time plain-library factorisation)
     roc.reset(new RocHandle());
     RBCHK(rocblas_set_stream(roc->h, st));
+    lap("rocBLAS handle");
     int ng = S.ng;
     ldm = (ng + 1) & ~1;
     if (opt.minv_mode < 0 || opt.minv_mode > 2) throw std::invalid_argument("minv_mode must be 0 (auto), 1 (dense) or 2 (structured)");
@@ -472,23 +494,27 @@ struct nnsdp_solver {
       if (mplan.ok) minv_structured = true;
       else if (opt.minv_mode == 2) throw std::invalid_argument("structured M^-1 not applicable: too few layers or the generator table is not block-banded by layer");
     }
-    if (minv_structured) build_structured_minv();
+    if (minv_structured) { build_structured_minv(); lap("structured M^-1"); }
     else {
       std::vector<double> M;
       build_M(S, M);
+      lap("M = I + A'D^-1A (host)");
       Minv.alloc((size_t)ldm * std::max(ng, 1));
       Minv.zero();
       HIPCHK(hipMemcpy2D(Minv.p, (size_t)ldm * sizeof(double), M.data(), (size_t)ng * sizeof(double), (size_t)ng * sizeof(double),
                          ng, hipMemcpyHostToDevice));
+    lap("M upload");
     DBuf<rocblas_int> info;
     info.alloc(1);
     RBCHK(rocsolver_dpotrf(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
     HIPCHK(hipStreamSynchronize(st));
     if (info.download()[0] != 0) throw HipError("Cholesky of M = I + A'D^-1A failed (potrf info != 0)");
+    lap("potrf");
     RBCHK(rocsolver_dpotri(roc->h, rocblas_fill_lower, ng, Minv.p, ldm, info.p));
     hipLaunchKernelGGL(k_symmetrize_lower, dim3(cdiv(ng, 256), ng), dim3(256), 0, st, ng, ldm, Minv.p);
     HIPCHK(hipStreamSynchronize(st));
     if (info.download()[0] != 0) throw HipError("inverse of M = I + A'D^-1A failed (potri info != 0)");
+    lap("potri + symmetrise");
     }
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
@@ -512,6 +538,7 @@ struct nnsdp_solver {
     HIPCHK(hipMemcpy(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice));
     if (lds_bytes > 64 * 1024) HIPCHK(proj_allow_big_lds());
     k0 = 0; k1 = ncl;
+    lap("state buffers");
     t_setup = now_s() - t_create0;
   }
 
@@ -749,7 +776,7 @@ struct nnsdp_solver {
   bool lead() const { return !sharded || rank == 0; }
 
   void enqueue_proj(bool warm) {
-    ProjArgs a;
+    ProjArgs a{};
     a.cn = d_cn.p + k0; a.coff = d_coff.p + k0; a.eoff = nullptr;
     a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr; a.Tg = Tg.p;
     a.kappa = d_kappa(); a.tol_dev = scal.p + 2; a.stats = d_stats.p;
@@ -998,7 +1025,10 @@ struct nnsdp_solver {
             o /= (S.zscale * S.cscale);
             double ref = std::max(std::fabs(last_pobj), std::fabs(last_dobj));
             if (opt.verbose) std::fprintf(stderr, "[nnsdp] it %6lld certified rho %.8g  admm %.8g  dual %.8g\n", iters_done, o, last_pobj, last_dobj);
-            if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) flag[0] = 1.0;
+            if (o - std::min(last_pobj, last_dobj) <= opt.cert_tol * ref && std::fabs(last_pobj - last_dobj) <= opt.cert_tol * ref) {
+              flag[0] = 1.0;
+              cert_gp = gp; cert_shift = polish_shift; cert_iter = iters_done;      // finish() reuses this polish (same iterate): 11 ms at W40-D20
+            }
           }
         } catch (const std::exception& e) {
           if (!sharded) throw;
@@ -1075,6 +1105,9 @@ struct nnsdp_solver {
   //   Z_aa - z_xa' Z_xx^-1 z_xa <= 0.
   // The result is a primal-feasible point: its objective is a valid (slightly conservative) bound.
   double polish_shift = 0.0, objective_admm = 0.0;
+  std::vector<double> cert_gp;       // polished multipliers of the check that stopped the solve (cert_tol rule), valid at iteration cert_iter
+  double cert_shift = 0.0;
+  long long cert_iter = -1;
   void dense_from_gs(const std::vector<double>& gsh, DBuf<double>& Zt) {
     int n = pat.n;
     DBuf<double> gd, zd;
@@ -1199,12 +1232,19 @@ struct nnsdp_solver {
       for (int i = 0; i < ng; ++i) o += S.c[i] * gsh[i];
       objective_admm = o / (S.zscale * S.cscale);
     }
+    const bool tm = std::getenv("NNSDP_SETUP_TIMING") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (tm) { const double t = now_s(); std::fprintf(stderr, "[nnsdp finish] %-28s %7.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
     polished = false;
     if (opt.polish) {
-      std::vector<double> gp = gsh;
-      polished = polish(gp);
-      if (polished) gsh = gp;
+      if (cert_iter == iters_done && cert_gp.size() == gsh.size()) { gsh = cert_gp; polish_shift = cert_shift; polished = true; }
+      else {
+        std::vector<double> gp = gsh;
+        polished = polish(gp);
+        if (polished) gsh = gp;
+      }
     }
+    lap("polish");
     gam.assign(P.ng, 0.0);
     for (int i = 0; i < ng; ++i) gam[S.keep[i]] = gsh[i] * S.ecol[i] / S.zscale;
     std::vector<int> elim;  // coordinates removed by the normalisation (full gamma index of their box multiplier): -> "large enough"
@@ -1223,7 +1263,9 @@ struct nnsdp_solver {
       double big = elim.empty() ? 0.0 : gscale * std::pow(100.0, trial + 1);
       for (int t : elim) gam[t] = big;
       full->assemble(gam, Zd, st);
+      lap("assemble Z(gamma)");
       lmax = lambda_max_dense(roc->h, Zd, P.Zdim);
+      lap("eigmax (dense)");
       if (lmax < best_l) { best_l = lmax; best_big = big; }
       if (lmax <= 1e-7 || (trial > 0 && lmax >= 0.9 * prev_l)) break;
       prev_l = lmax;
@@ -1238,9 +1280,12 @@ struct nnsdp_solver {
   void finish(nnsdp_result* r, int status) {
     // final Z and certificate in the reference's coordinates
     if (!full) {
-      full.reset(new FullOperator());
-      nnsdp_problem pp = problem_view();
-      full->build(&pp);
+      if (full_fut.valid()) { full = full_fut.get(); full->upload(); }
+      else {
+        full.reset(new FullOperator());
+        nnsdp_problem pp = problem_view();
+        full->build(&pp);
+      }
     }
     std::vector<double> gam(P.ng, 0.0);
     DBuf<double> Zd;
@@ -1402,7 +1447,7 @@ struct nnsdp_batch {
         gx_nb = std::max(gx_nb, (int)nb);
       }
       it.push_back(a);
-      ProjArgs q;
+      ProjArgs q{};
       q.cn = s->d_cn.p; q.coff = s->d_coff.p; q.eoff = nullptr;
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
@@ -1891,7 +1936,7 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   bool v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
-  ProjArgs a;
+  ProjArgs a{};
   a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p; a.Tg = nullptr;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0; a.refine_loose = 1.0; a.refine_pivots = 0;
@@ -1972,7 +2017,7 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   bool v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
-  ProjArgs a;
+  ProjArgs a{};
   a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
   a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0; a.refine_pivots = 2;

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   const bool blockmode = alg == 1;
   bool v_lds = proj_lds_bytes(n, true, alg) <= 160 * 1024; size_t lds = proj_lds_bytes(n, v_lds, alg);
   proj_allow_big_lds();
-  ProjArgs a; a.cn = dcn; a.coff = dco; a.eoff = deo; a.nu = dnu; a.w = dw; a.Vg = dV; a.eig = dE; a.kappa = nullptr; a.tol_dev = nullptr; int* dstats; hipMalloc(&dstats, 16); a.stats = dstats; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
+  ProjArgs a{}; a.cn = dcn; a.coff = dco; a.eoff = deo; a.nu = dnu; a.w = dw; a.Vg = dV; a.eig = dE; a.kappa = nullptr; a.tol_dev = nullptr; int* dstats; hipMalloc(&dstats, 64); a.stats = dstats; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; ++rep) {
     if (rep >= 2) {  // warm regime: perturb the matrices slightly, start from the stored eigenvectors, solver tolerance
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
       hipMemcpy(dnu, h.data(), h.size() * 8, hipMemcpyHostToDevice);
       a.warm = 1; a.tol = argc > 4 ? atof(argv[4]) : 1e-6;
     }
-    hipMemset(dstats, 0, 16);
+    hipMemset(dstats, 0, 64);
     hipEventRecord(e0); launch_proj(a, batch, n, v_lds, lds, nullptr, alg); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long dbg[70] = {0}; hipMemcpy(dbg, dE + 4096, sizeof(dbg), hipMemcpyDeviceToHost);
