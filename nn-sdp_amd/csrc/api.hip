@@ -1937,7 +1937,9 @@ int nnsdp_project_psd_batched(int32_t batch, const int32_t* n, const double* mat
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a{};
-  a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p; a.Tg = nullptr;
+  DBuf<double> dT;
+  if (alg == nnsdp::kProjPacked) dT.alloc(tot);       // the packed variant's sweeps log their rotations there
+  a.cn = dcn.p; a.coff = dco.p; a.eoff = deo.p; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = dE.p; a.Tg = dT.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = nullptr; a.warm = 0; a.max_sweeps = 30; a.tol = 1e-13;
   a.refine = 0; a.rstate = nullptr; a.refine_acc = 0.0; a.refine_kcap = 0.0; a.refine_loose = 1.0; a.refine_pivots = 0;
   hipEvent_t e0, e1;

@@ -1654,6 +1654,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       ++sweeps;
     }
   } else {
+  double* const Tlog = PK ? a.Tg + a.coff[k] : nullptr;     // packed variant: the sweep's rotation log (the warm-start scratch, free by now)
   for (;;) {
     // direct measurement of off(A)^2 (no cancellation): ~1/40 of a sweep
     double off2 = 0.0;
@@ -1727,6 +1728,12 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           dd[0] = c; dd[1] = s;
           reinterpret_cast<int*>(dd + 2)[0] = p; reinterpret_cast<int*>(dd + 2)[1] = q;
         }
+      } else if constexpr (PK) {
+        // packed variant: the eigenvectors live in HBM / L2, and rotating them there every round (the whole V read and written 151
+        // times per sweep through one CU's ~25 KB in flight) was 5/6 of the sweep.  The rounds only LOG their (c, s) - the first
+        // M - 1 of them into the warm-start scratch (exactly (np - 2) half 2 <= n^2 doubles; the last round's are still in LDS when
+        // the sweep ends) - and V takes all rotations of the sweep afterwards, 16 rows at a time through LDS (below).
+        if (r < M - 1 && tid < 2 * half) Tlog[(size_t)r * 2 * half + tid] = dsc[4 * (tid >> 1) + (tid & 1)];
       } else {
         {
 #pragma unroll
@@ -1753,6 +1760,58 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       STAMP(3, tprev)
       buf ^= 1;
     }
+    RST(15)
+    if constexpr (PK) {
+      // V <- V J_0 J_1 ... J_{M-1}, 32 rows at a time through LDS: thread = (row, stream), stream s takes the pair slots s, s + 32, ...
+      // of every round (the pairs of a round are disjoint; one barrier per round orders the rounds); the (c, s) of kLogBatch rounds at a
+      // time are staged in LDS (next batch prefetched into registers while this one runs).  Panel stride 161: the 32 rows of a column
+      // sit in 32 different banks.  Panels are loaded and stored as 256-byte pieces of V's columns.
+      constexpr int kLogBatch = 4, kPanelLd = 161, kRows = 32;
+      double* const Pn = red + 16 + (npg >> 1) + 2;                   // kRows x kPanelLd panel
+      double* const ring = Pn + kRows * kPanelLd;                     // 2 x kLogBatch x 2 half
+      const double* const lastdsc = desc + ((M - 1) & 1) * 4 * half;  // parameters of the sweep's last round
+      const int prow = tid & (kRows - 1), stream = tid >> 5;
+      const int per = 2 * half, nbatch = (M + kLogBatch - 1) / kLogBatch;
+      // this thread's entry of batch b of the log (kLogBatch x 2 half <= 640 doubles: threads [0, 640))
+      const int e_r = tid / per, e_w = tid - e_r * per;
+      auto fetch = [&](int b) {
+        const int r = b * kLogBatch + e_r;
+        double v = 0.0;
+        if (tid < kLogBatch * per && r < M) v = r < M - 1 ? Tlog[(size_t)r * per + e_w] : lastdsc[4 * (e_w >> 1) + (e_w & 1)];
+        return v;
+      };
+      for (int g0 = 0; g0 < n; g0 += kRows) {
+        for (int j = tid >> 5; j < n; j += NT >> 5) { const int i = g0 + prow; Pn[prow * kPanelLd + j] = i < n ? V[i + (size_t)j * ldv] : 0.0; }
+        double st = fetch(0);
+        if (tid < kLogBatch * per) ring[tid] = st;
+        __syncthreads();
+        double* const row = Pn + prow * kPanelLd;
+        for (int b = 0; b < nbatch; ++b) {
+          if (b + 1 < nbatch) st = fetch(b + 1);
+          const double* cs = ring + (b & 1) * kLogBatch * per;
+          const int r1 = min(kLogBatch, M - b * kLogBatch);
+          for (int rr = 0; rr < r1; ++rr) {
+            const int r = b * kLogBatch + rr;
+            // (requesting the operands of the thread's three pairs together before writing any - one LDS round trip per round - costs 13
+            // spilled VGPRs and is slower, 1.58 M against 1.44 M cycles per sweep: the rounds are bound by instruction issue, 16 waves on 4 SIMDs)
+            for (int slot = stream; slot < half; slot += NT >> 5) {
+              const double c = cs[rr * per + 2 * slot], sn = cs[rr * per + 2 * slot + 1];
+              const int p_ = pair_top(slot, r, M, half), q_ = pair_bot(slot, r, M, half);
+              if (p_ < nv && q_ < nv) {       // padded index: the rotation is the identity
+                const double xp = row[p_], xq = row[q_];
+                row[p_] = c * xp - sn * xq;
+                row[q_] = sn * xp + c * xq;
+              }
+            }
+            if (rr == r1 - 1 && b + 1 < nbatch && tid < kLogBatch * per) ring[((b + 1) & 1) * kLogBatch * per + tid] = st;   // (the other half: nobody reads it in batch b)
+            __syncthreads();
+          }
+        }
+        for (int j = tid >> 5; j < n; j += NT >> 5) { const int i = g0 + prow; if (i < n) V[i + (size_t)j * ldv] = Pn[prow * kPanelLd + j]; }
+        __syncthreads();
+      }
+    }
+    RST(16)
     ++sweeps;
   }
   }
@@ -1843,6 +1902,59 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
       }
     }
+  } else if constexpr (PK) {
+    // packed variant: W = sum_t lam_t v_t v_t' on the matrix cores, the selected eigenvectors staged through LDS 16 at a time
+    // (k-major panel in the space the sweeps' eigenvector panel used; every thread re-reading its 2 nsel operands from L2 - the form
+    // below - was 16 % of a warm launch of the 151-wide blocks).  Lower tiles, four per wave at most (55 tiles at n = 160).
+    constexpr int NW = NT / 64, kPanelLd = 161, kTilesPerWave = 4;
+    double* const Pn = red + 16 + (npg >> 1) + 2;       // 16 x kPanelLd
+    double* const lamc = Pn + 16 * kPanelLd;            // the chunk's 16 eigenvalues (0 past the selection)
+    const int nt = (n + 15) >> 4, ntl = nt * (nt + 1) / 2;
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lc = lane >> 4;
+    int tti[kTilesPerWave], ttj[kTilesPerWave];
+    d4_t acc[kTilesPerWave];
+#pragma unroll
+    for (int m = 0; m < kTilesPerWave; ++m) {
+      const int t = wv + m * NW;
+      int ti = -1, tj = -1;
+      if (t < ntl) { ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ++ti; tj = t - ti * (ti + 1) / 2; }
+      tti[m] = ti; ttj[m] = tj;
+      acc[m] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    __syncthreads();      // (the selection list is complete; the panel space is free)
+    for (int c0 = 0; c0 < nsel; c0 += 16) {
+      {
+        const int kk = tid >> 6, l = c0 + kk < nsel ? sel[c0 + kk] : -1;
+        for (int i = tid & 63; i < 16 * nt; i += 64) Pn[kk * kPanelLd + i] = (l >= 0 && i < n) ? V[i + (size_t)l * ldv] : 0.0;
+        if ((tid & 63) == 0) lamc[kk] = l >= 0 ? A[ixl(l, l)] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < kTilesPerWave; ++m)
+        if (tti[m] >= 0) {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int kx = 4 * k4 + lc;
+            const double av = lamc[kx] * Pn[kx * kPanelLd + 16 * tti[m] + lr], bv = Pn[kx * kPanelLd + 16 * ttj[m] + lr];
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[m], 0, 0, 0);
+          }
+        }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < kTilesPerWave; ++m)
+      if (tti[m] >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tti[m] + lc + 4 * r, col = 16 * ttj[m] + lr;
+          if (row < n && col < n) {
+            double v = acc[m][r];
+            if (!use_pos) v = 0.5 * (nuk[(size_t)col * n + row] + nuk[(size_t)row * n + col]) - v;
+            wk[(size_t)col * n + row] = v;
+            if (tti[m] != ttj[m]) wk[(size_t)row * n + col] = v;
+          }
+        }
+      }
   } else {
     for (int j = tid >> 6; j < n; j += NT >> 6)
       for (int i = tid & 63; i < n; i += 64) {
@@ -1868,6 +1980,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   }
 #ifdef NNSDP_STAMPS
   if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
+  if (PK && k == 0 && tid == 0 && !a.eig)
+    printf("[stamps packed n=%d] (last sweep: V update %lld) load %lld congruence %lld sweeps %lld (%d) select %lld reconstruct + stores %lld | total %lld\n", n, rst[16] - rst[15], sec_t[1] - sec_t[0], sec_t[2] - sec_t[1],
+           sec_t[3] - sec_t[2], sweeps, rst[10] - sec_t[3], clock64() - rst[10], clock64() - sec_t[0]);
   if (PP && k == 0 && (tid == 0 || tid == NT - 64) && !a.eig) {
     const long long te = clock64();
     printf("[stamps n=%d wave %d] (load: to LDS %lld barrier %lld symmetrise %lld sum %lld) load %lld congruence %lld to-stage %lld | gram %lld diag %lld analyse %lld | E~ %lld sums %lld E~^2 %lld V-update %lld lambda %lld | to-select %lld select %lld W %lld V-store %lld | total %lld\n",
@@ -1966,8 +2081,8 @@ inline hipError_t proj_allow_big_lds() {
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
   int np = (nmax + 15) & ~15;
-  if (alg == kProjPacked)    // packed lower triangle, desc[2][half][4], red, sel
-    return ((((size_t)np * (np + 1)) / 2 + 1) + 4 * (size_t)np + 16 + (np >> 1) + 2 + 2) * sizeof(double);
+  if (alg == kProjPacked)    // packed lower triangle, desc[2][half][4], red, sel, the 32-row eigenvector panel (stride 161) and the rotation-log ring (2 x 4 rounds)
+    return ((((size_t)np * (np + 1)) / 2 + 1) + 4 * (size_t)np + 16 + (np >> 1) + 2 + 2 + 32 * 161 + 2 * 4 * (size_t)np) * sizeof(double);
   if (alg == kProjSystolic) {
     size_t am = ((size_t)np * (np + 1) + 1) & ~(size_t)1;
     size_t d = am + (v_lds ? (size_t)np * (np + 1) : 0);
