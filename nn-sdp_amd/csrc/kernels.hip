@@ -441,62 +441,90 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   if (warm && V_LDS) {
     congruence();
   } else if (warm && PK) {
-    // A <- V' A V for the packed variant: T = A V into the HBM scratch (A read through the packed triangle), then the lower triangle of
-    // B = T' V (= V' T: B is symmetric) straight into the packed storage; 4 x 2 register tiles.  T is stored ROW-major so that the four
-    // rows of a tile in the second product are contiguous across the lanes of a wave (the column of V is a broadcast): stored
-    // column-major like V, every lane walked its own cache line and the second product cost as much as a sweep
-    constexpr int kTiles = 4;                          // (160 / 4) * (160 / 2) = 3200 tiles over 1024 threads
-    const int ti_n = (n + 3) >> 2, tj_n = (n + 1) >> 1;
-    double* Tk = a.Tg + a.coff[k];
-    for (int m = 0; m < kTiles; ++m) {
-      const int t = tid + m * NT;
-      const int tj = t / ti_n, ti = t - tj * ti_n;
-      if (tj < tj_n) {
-        const int i0 = ti * 4, j0 = tj * 2;
-        const int i1 = min(i0 + 1, n - 1), i2 = min(i0 + 2, n - 1), i3 = min(i0 + 3, n - 1), j1 = min(j0 + 1, n - 1);
-        const double* v0 = V + (size_t)j0 * ldv;
-        const double* v1 = V + (size_t)j1 * ldv;
-        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-        for (int l = 0; l < n; ++l) {
-          const double x0 = v0[l], x1 = v1[l];
-          const double y0 = A[ixs(i0, l)], y1 = A[ixs(i1, l)], y2 = A[ixs(i2, l)], y3 = A[ixs(i3, l)];
-          c0 += y0 * x0; c1 += y1 * x0; c2 += y2 * x0; c3 += y3 * x0;
-          d0 += y0 * x1; d1 += y1 * x1; d2 += y2 * x1; d3 += y3 * x1;
-        }
-        const double cc[4] = {c0, c1, c2, c3}, dd[4] = {d0, d1, d2, d3};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (i0 + r < n) { Tk[(size_t)(i0 + r) * n + j0] = cc[r]; if (j0 + 1 < n) Tk[(size_t)(i0 + r) * n + j0 + 1] = dd[r]; }
+    // A <- V' A V for the packed variant, both products on the matrix cores with the streamed operand staged through LDS ONCE:
+    //   pass 1  T[:, J] = A V[:, J] for 32-column panels J of V (panel in LDS, A read through the packed triangle), T row-major into
+    //           the HBM scratch;
+    //   pass 2  B = T'V (= V'T: B is symmetric) accumulated over chunks of 16 rows l of T and V (both chunks in LDS: rows of the
+    //           row-major T are contiguous, 16 consecutive l of a column of V are one 128-byte line), lower tiles, four per wave,
+    //           written into the packed storage at the end (A is dead once pass 1 is through).
+    // (The first form - 4 x 2 register tiles on the vector pipe, every thread streaming its operands from L2 - took 1.05 M cycles of
+    // a 151-wide block's 4.9 M per warm launch.)
+    constexpr int NW = NT / 64, kPanelLd = 161;
+    double* const Pn = red + 16 + (npg >> 1) + 2;        // 32 x kPanelLd doubles
+    double* const Tk = a.Tg + a.coff[k];
+    const int nt = (n + 15) >> 4, ks = (n + 3) >> 2;
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lc = lane >> 4;
+    for (int j0 = 0; j0 < n; j0 += 32) {
+      {
+        const int jl = tid >> 5;                           // 32 threads per column, 32 columns
+        for (int kx = tid & 31; kx < 4 * ks; kx += 32) Pn[jl * kPanelLd + kx] = (j0 + jl < n && kx < n) ? V[kx + (size_t)(j0 + jl) * ldv] : 0.0;
       }
-    }
-    __syncthreads();     // (every read of A is done, and the block's writes of T are visible to the block)
-    for (int m = 0; m < kTiles; ++m) {
-      const int t = tid + m * NT;
-      const int tj = t / ti_n, ti = t - tj * ti_n;
-      if (tj < tj_n) {
-        const int i0 = ti * 4, j0 = tj * 2;
-        if (i0 + 3 >= j0) {                            // tiles with an entry on or below the diagonal
-          const int i1 = min(i0 + 1, n - 1), i2 = min(i0 + 2, n - 1), i3 = min(i0 + 3, n - 1), j1 = min(j0 + 1, n - 1);
-          const double *w0 = V + (size_t)j0 * ldv, *w1 = V + (size_t)j1 * ldv;
-          double c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-          for (int l = 0; l < n; ++l) {
-            const double x0 = w0[l], x1 = w1[l];                       // V(l, j0), V(l, j0 + 1): the same for the whole wave
-            const double* tr = Tk + (size_t)l * n;                     // row l of T: T(l, i0 .. i0 + 3), contiguous across the lanes
-            const double y0 = tr[i0], y1 = tr[i1], y2 = tr[i2], y3 = tr[i3];
-            c0 += y0 * x0; c1 += y1 * x0; c2 += y2 * x0; c3 += y3 * x0;
-            d0 += y0 * x1; d1 += y1 * x1; d2 += y2 * x1; d3 += y3 * x1;
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int t = wv + m * NW, hh = t / nt, ti = t - hh * nt;      // (row tile, 16-column half of the panel)
+        if (hh < 2 && j0 + 16 * hh < n) {
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+          const int i = 16 * ti + lr;
+          const double* bp = Pn + (16 * hh + lr) * kPanelLd + lc;
+          for (int kk = 0; kk < ks; ++kk) {
+            const int kx = 4 * kk + lc;
+            const double av = (i < n && kx < n) ? A[ixs(i, kx)] : 0.0;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[4 * kk], c, 0, 0, 0);
           }
-          const double cc[4] = {c0, c1, c2, c3}, dd[4] = {d0, d1, d2, d3};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int i = i0 + r;
-            if (i < n) {
-              if (i >= j0) A[ixl(i, j0)] = cc[r];
-              if (j0 + 1 < n && i >= j0 + 1) A[ixl(i, j0 + 1)] = dd[r];
-            }
+            const int row = 16 * ti + lc + 4 * r, col = j0 + 16 * hh + lr;
+            if (row < n && col < n) Tk[(size_t)row * n + col] = c[r];
           }
         }
       }
+      __syncthreads();
+    }
+    // (every read of A is done, and the block's writes of T are visible to the block)
+    {
+      constexpr int kTilesPerWave = 4;
+      const int ntl = nt * (nt + 1) / 2;
+      double* const Tc = Pn;
+      double* const Vc = Pn + 16 * kPanelLd;
+      int tti[kTilesPerWave], ttj[kTilesPerWave];
+      d4_t acc[kTilesPerWave];
+#pragma unroll
+      for (int m = 0; m < kTilesPerWave; ++m) {
+        const int t = wv + m * NW;
+        int ti = -1, tj = -1;
+        if (t < ntl) { ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ++ti; tj = t - ti * (ti + 1) / 2; }
+        tti[m] = ti; ttj[m] = tj;
+        acc[m] = d4_t{0.0, 0.0, 0.0, 0.0};
+      }
+      for (int l0 = 0; l0 < n; l0 += 16) {
+        {
+          const int ll = tid >> 6, l = l0 + ll;              // T: one wave per row l, lanes along i
+          for (int i = tid & 63; i < 16 * nt; i += 64) Tc[ll * kPanelLd + i] = (l < n && i < n) ? Tk[(size_t)l * n + i] : 0.0;
+          const int lv = tid & 15, l2 = l0 + lv;             // V: 16 lanes along l (one line), columns j
+          for (int j = tid >> 4; j < 16 * nt; j += NT >> 4) Vc[lv * kPanelLd + j] = (l2 < n && j < n) ? V[l2 + (size_t)j * ldv] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kTilesPerWave; ++m)
+          if (tti[m] >= 0) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+              const int kx = 4 * k4 + lc;
+              acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(Tc[kx * kPanelLd + 16 * tti[m] + lr], Vc[kx * kPanelLd + 16 * ttj[m] + lr], acc[m], 0, 0, 0);
+            }
+          }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int m = 0; m < kTilesPerWave; ++m)
+        if (tti[m] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tti[m] + lc + 4 * r, col = 16 * ttj[m] + lr;
+            if (row < n && col <= row) A[ixl(row, col)] = acc[m][r];
+          }
+        }
     }
     __syncthreads();
   } else if (warm) {
