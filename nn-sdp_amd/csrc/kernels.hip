@@ -1800,7 +1800,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       const double* const lastdsc = desc + ((M - 1) & 1) * 4 * half;  // parameters of the sweep's last round
       const int prow = tid & (kRows - 1), stream = tid >> 5;
       const int per = 2 * half, nbatch = (M + kLogBatch - 1) / kLogBatch;
-      // this thread's entry of batch b of the log (kLogBatch x 2 half <= 640 doubles: threads [0, 640))
+      // this thread's entry of batch b of the log (kLogBatch x 2 half <= 640 doubles: threads [0, 640)); the pair's two indices ride
+      // along in a third ring plane, computed once per slot and round here instead of once per ROW by every thread of the panel
       const int e_r = tid / per, e_w = tid - e_r * per;
       auto fetch = [&](int b) {
         const int r = b * kLogBatch + e_r;
@@ -1808,30 +1809,44 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         if (tid < kLogBatch * per && r < M) v = r < M - 1 ? Tlog[(size_t)r * per + e_w] : lastdsc[4 * (e_w >> 1) + (e_w & 1)];
         return v;
       };
+      int* const ringpq = reinterpret_cast<int*>(ring + 2 * kLogBatch * per);      // 2 x kLogBatch x half packed (p << 16 | q), -1: identity
+      auto stash_pq = [&](int b) {
+        const int r = b * kLogBatch + tid / half, slot = tid % half;
+        if (tid < kLogBatch * half) {
+          int v = -1;
+          if (r < M) { const int pp = pair_top(slot, r, M, half), qq = pair_bot(slot, r, M, half); if (pp < nv && qq < nv) v = (pp << 16) | qq; }
+          ringpq[(b & 1) * kLogBatch * half + tid] = v;
+        }
+      };
       for (int g0 = 0; g0 < n; g0 += kRows) {
         for (int j = tid >> 5; j < n; j += NT >> 5) { const int i = g0 + prow; Pn[prow * kPanelLd + j] = i < n ? V[i + (size_t)j * ldv] : 0.0; }
         double st = fetch(0);
         if (tid < kLogBatch * per) ring[tid] = st;
+        stash_pq(0);
         __syncthreads();
         double* const row = Pn + prow * kPanelLd;
         for (int b = 0; b < nbatch; ++b) {
           if (b + 1 < nbatch) st = fetch(b + 1);
           const double* cs = ring + (b & 1) * kLogBatch * per;
+          const int* pqs = ringpq + (b & 1) * kLogBatch * half;
           const int r1 = min(kLogBatch, M - b * kLogBatch);
           for (int rr = 0; rr < r1; ++rr) {
-            const int r = b * kLogBatch + rr;
             // (requesting the operands of the thread's three pairs together before writing any - one LDS round trip per round - costs 13
             // spilled VGPRs and is slower, 1.58 M against 1.44 M cycles per sweep: the rounds are bound by instruction issue, 16 waves on 4 SIMDs)
             for (int slot = stream; slot < half; slot += NT >> 5) {
-              const double c = cs[rr * per + 2 * slot], sn = cs[rr * per + 2 * slot + 1];
-              const int p_ = pair_top(slot, r, M, half), q_ = pair_bot(slot, r, M, half);
-              if (p_ < nv && q_ < nv) {       // padded index: the rotation is the identity
+              const int pq = pqs[rr * half + slot];
+              if (pq >= 0) {                  // (padded index: the rotation is the identity)
+                const double c = cs[rr * per + 2 * slot], sn = cs[rr * per + 2 * slot + 1];
+                const int p_ = pq >> 16, q_ = pq & 0xffff;
                 const double xp = row[p_], xq = row[q_];
                 row[p_] = c * xp - sn * xq;
                 row[q_] = sn * xp + c * xq;
               }
             }
-            if (rr == r1 - 1 && b + 1 < nbatch && tid < kLogBatch * per) ring[((b + 1) & 1) * kLogBatch * per + tid] = st;   // (the other half: nobody reads it in batch b)
+            if (rr == r1 - 1 && b + 1 < nbatch) {      // (the other ring half: nobody reads it in batch b)
+              if (tid < kLogBatch * per) ring[((b + 1) & 1) * kLogBatch * per + tid] = st;
+              stash_pq(b + 1);
+            }
             __syncthreads();
           }
         }
@@ -2109,8 +2124,8 @@ inline hipError_t proj_allow_big_lds() {
 
 inline size_t proj_lds_bytes(int nmax, bool v_lds, int alg = kProjRoundRobin) {
   int np = (nmax + 15) & ~15;
-  if (alg == kProjPacked)    // packed lower triangle, desc[2][half][4], red, sel, the 32-row eigenvector panel (stride 161) and the rotation-log ring (2 x 4 rounds)
-    return ((((size_t)np * (np + 1)) / 2 + 1) + 4 * (size_t)np + 16 + (np >> 1) + 2 + 2 + 32 * 161 + 2 * 4 * (size_t)np) * sizeof(double);
+  if (alg == kProjPacked)    // packed lower triangle, desc[2][half][4], red, sel, the 32-row eigenvector panel (stride 161) and the rotation-log ring (2 x 4 rounds of (c, s) and of the packed pair indices)
+    return ((((size_t)np * (np + 1)) / 2 + 1) + 4 * (size_t)np + 16 + (np >> 1) + 2 + 2 + 32 * 161 + 10 * (size_t)np) * sizeof(double);
   if (alg == kProjSystolic) {
     size_t am = ((size_t)np * (np + 1) + 1) & ~(size_t)1;
     size_t d = am + (v_lds ? (size_t)np * (np + 1) : 0);
