@@ -313,7 +313,7 @@ struct nnsdp_solver {
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
   DBuf<unsigned int> d_gidx;
-  DBuf<double> Tg;
+  DBuf<double> Tg, Ug;
   DBuf<double> nu, w, Vg, x, g, p, qv, ww, Minv, scal /* sigma, kappa */, acc /* 8 control numbers | ng multipliers (sharded resync) */, gs;
   DBuf<double> accp;                    // per-workgroup partial sums of the residual quantities: [7][acc_stride]
   int acc_stride = 0, nb_upd = 0, nb_dual = 0, nb_obj = 0;
@@ -518,7 +518,7 @@ struct nnsdp_solver {
     }
     // iteration state
     nu.alloc(ng + nmat); w.alloc(ng + nmat); Vg.alloc(nmat);
-    if (proj_alg == nnsdp::kProjPacked) { Tg.alloc(nmat); Tg.zero(); }      // warm-start scratch of the packed variant
+    if (proj_alg == nnsdp::kProjPacked) { Tg.alloc(nmat); Tg.zero(); Ug.alloc(nmat); Ug.zero(); }      // scratch of the packed variant (warm start, rotation log; new basis of its refinement stage)
     x.alloc(S.NE); g.alloc(S.NE); p.alloc(ng); qv.alloc(ldm); ww.alloc(ng); gs.alloc(ng);
     scal.alloc(4); acc.alloc(8 + (size_t)ng); acc.zero();
     nb_upd = cdiv(ng + nmat, kThreads);
@@ -778,7 +778,7 @@ struct nnsdp_solver {
   void enqueue_proj(bool warm) {
     ProjArgs a{};
     a.cn = d_cn.p + k0; a.coff = d_coff.p + k0; a.eoff = nullptr;
-    a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr; a.Tg = Tg.p;
+    a.nu = nu.p + S.ng; a.w = w.p + S.ng; a.Vg = Vg.p; a.eig = nullptr; a.Tg = Tg.p; a.Ug = Ug.p;
     a.kappa = d_kappa(); a.tol_dev = scal.p + 2; a.stats = d_stats.p;
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
@@ -1449,7 +1449,7 @@ struct nnsdp_batch {
       it.push_back(a);
       ProjArgs q{};
       q.cn = s->d_cn.p; q.coff = s->d_coff.p; q.eoff = nullptr;
-      q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p;
+      q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p; q.Ug = s->Ug.p;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
       q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap; q.refine_loose = s->refine_loose; q.refine_pivots = s->refine_pivots;
@@ -1477,8 +1477,10 @@ struct nnsdp_batch {
     nmax = std::max(nmax, 1);
     alg = proj_algorithm(nmax);
     if (alg == nnsdp::kProjPacked)          // one launch for all members in the packed variant: every member needs its warm-start scratch
-      for (size_t b = 0; b < act.size(); ++b)
+      for (size_t b = 0; b < act.size(); ++b) {
         if (!act[b]->Tg.p) { act[b]->Tg.alloc(act[b]->nmat); act[b]->Tg.zero(); pw[b].Tg = pc[b].Tg = act[b]->Tg.p; }
+        if (!act[b]->Ug.p) { act[b]->Ug.alloc(act[b]->nmat); act[b]->Ug.zero(); pw[b].Ug = pc[b].Ug = act[b]->Ug.p; }
+      }
     v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
     lds = proj_lds_bytes(nmax, v_lds, alg);
     if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
@@ -2008,9 +2010,9 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
     nmax = std::max(nmax, cn[b]);
   }
   coff[batch] = tot;
-  DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV, dT;
+  DBuf<int> dcn, dst, drs; DBuf<long long> dco; DBuf<double> dnu, dw, dV, dT, dU;
   dcn.upload(cn); dco.upload(coff);
-  dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dT.alloc(tot);
+  dnu.alloc(tot); dw.alloc(tot); dV.alloc(tot); dT.alloc(tot); dU.alloc(tot);
   dst.alloc(14); dst.zero(); drs.alloc(4 * (size_t)batch); drs.zero();
   if (state) HIPCHK(hipMemcpy(drs.p, state, 4 * (size_t)batch * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
@@ -2020,7 +2022,7 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
   ProjArgs a{};
-  a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p;
+  a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p; a.Ug = dU.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
   a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0; a.refine_pivots = 2;
   if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);

@@ -93,6 +93,7 @@ struct ProjArgs {
   double* Vg;             // packed eigenvectors (in for warm start, out)
   double* eig;            // packed eigenvalues (out, may be null)
   double* Tg;             // scratch of the size of Vg for the packed variant's warm start (blocks 129 .. 160; may be null otherwise)
+  double* Ug;             // second scratch of that size: the packed variant's refinement stage writes the new basis there (null: no stage)
   const double* kappa;    // device scalar: nu <- w + kappa (nu - w) (penalty change), may be null
   const double* tol_dev;  // device scalar overriding tol (lets the host adapt it between graph launches), may be null
   int* stats;             // [0] += sweeps used (atomic), [1] = max sweeps seen, [2..3] rotation counts, [4..8] refinement stage: blocks
@@ -438,9 +439,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       __syncthreads();
     }
   };
-  if (warm && V_LDS) {
-    congruence();
-  } else if (warm && PK) {
+  auto pk_congruence = [&]() {
     // A <- V' A V for the packed variant, both products on the matrix cores with the streamed operand staged through LDS ONCE:
     //   pass 1  T[:, J] = A V[:, J] for 32-column panels J of V (panel in LDS, A read through the packed triangle), T row-major into
     //           the HBM scratch;
@@ -527,6 +526,11 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
     }
     __syncthreads();
+  };
+  if (warm && V_LDS) {
+    congruence();
+  } else if (warm && PK) {
+    pk_congruence();
   } else if (warm) {
     // (blocks too large to keep V in LDS) A <- V' A V as two register-tiled products (4 x 2 tiles, accumulators in VGPRs):
     //   T = A V   (written over A),   A' = V' T   (written over T)
@@ -1073,6 +1077,277 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
       }
     } else if (warm && rmode != 0 && wait > 0 && tid == 0) {
+      a.rstate[4 * k] = (gcred << 24) | (credit << 16) | (level << 8) | (wait - 1);
+      if (a.stats) atomicAdd(&a.stats[7], 1);
+    }
+  }
+  // ---- refinement stage of the packed variant (blocks 129 .. 160).  The same step as above in the form these sizes allow: the basis
+  // lives in HBM / L2 and the packed triangle has no room for a second triangle, so the rotation is the antisymmetric K alone
+  // (K_ij = B_ij / (d_j - d_i) in the packed triangle, K_ji = -K_ij implied), orthogonality is restored by a separate pass
+  // V <- V (I + R / 2) on the visits that measure the Gram matrix and find a defect worth removing, and every product streams its
+  // operands once through the 32 x 161 LDS panel: X = I + K + K^2 / 2 (both factors gathered from the packed LDS) goes to the n^2
+  // scratch, V X to the second scratch and back.  Same acceptance rule, same state word, the packed sweeps as the exact fall-back.
+  if constexpr (PK) {
+    int wait = 0, level = 0, credit = 0, gcred = 0;
+    double rdef = 0.0;
+    if (a.rstate) {
+      const int rs = a.rstate[4 * k]; wait = rs & 255; level = (rs >> 8) & 255; credit = (rs >> 16) & 255; gcred = (rs >> 24) & 15;
+      rdef = *reinterpret_cast<const double*>(a.rstate + 4 * k + 2);
+    }
+    __syncthreads();      // (every wave has the state word before thread 0 rewrites it: see the ping-pong stage)
+    const int rmode = a.refine;
+    if (warm && rmode != 0 && a.Ug && wait == 0) {
+      constexpr int NW = NT / 64, kPanelLd = 161, kTilesPerWave = 4;
+      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lc = lane >> 4;
+      const int nt = (n + 15) >> 4, ntl = nt * (nt + 1) / 2, ks = (n + 3) >> 2;
+      double* const Pn = red + 16 + (npg >> 1) + 2;
+      double* const Tk = a.Tg + a.coff[k];
+      double* const Uk = a.Ug + a.coff[k];
+      double* const dvec = desc;                 // B_ii
+      double* const cs1 = desc + npg;            // column sums of K^2
+      double* const cs2 = desc + 2 * npg;        // column sums of K^2 d
+      double* const nrm = desc + 3 * npg;        // squared column norms of the new basis
+      int tti[kTilesPerWave], ttj[kTilesPerWave];
+#pragma unroll
+      for (int m = 0; m < kTilesPerWave; ++m) {
+        const int t = wv + m * NW;
+        int ti = -1, tj = -1;
+        if (t < ntl) { ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ++ti; tj = t - ti * (ti + 1) / 2; }
+        tti[m] = ti; ttj[m] = tj;
+      }
+      // V <- V M with M (n x n, row-major, identity included) in the first scratch: 16-column chunks of V against 16-row chunks of M,
+      // all n^2 output tiles in two halves of the tile columns (four accumulators per wave), the result through the second scratch;
+      // the copy back also takes the squared column norms
+      auto apply_M = [&]() {
+        const int hsplit = (nt + 1) >> 1;
+        for (int hcol = 0; hcol < 2; ++hcol) {
+          const int tj0 = hcol ? hsplit : 0, ntile = nt * (hcol ? nt - hsplit : hsplit);
+          d4_t acc[kTilesPerWave];
+#pragma unroll
+          for (int m = 0; m < kTilesPerWave; ++m) acc[m] = d4_t{0.0, 0.0, 0.0, 0.0};
+          double* const Vc = Pn;
+          double* const Mc = Pn + 16 * kPanelLd;
+          for (int l0 = 0; l0 < n; l0 += 16) {
+            {
+              const int ll = tid >> 6, l = l0 + ll;
+              for (int i = tid & 63; i < 16 * nt; i += 64) {
+                Vc[ll * kPanelLd + i] = (l < n && i < n) ? V[i + (size_t)l * ldv] : 0.0;
+                Mc[ll * kPanelLd + i] = (l < n && i < n) ? Tk[(size_t)l * n + i] : 0.0;
+              }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < kTilesPerWave; ++m) {
+              const int t = wv + m * NW;
+              if (t < ntile) {
+                const int tjl = t / nt, ti = t - tjl * nt, tj = tj0 + tjl;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                  const int kx = 4 * k4 + lc;
+                  acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vc[kx * kPanelLd + 16 * ti + lr], Mc[kx * kPanelLd + 16 * tj + lr], acc[m], 0, 0, 0);
+                }
+              }
+            }
+            __syncthreads();
+          }
+#pragma unroll
+          for (int m = 0; m < kTilesPerWave; ++m) {
+            const int t = wv + m * NW;
+            if (t < ntile) {
+              const int tjl = t / nt, ti = t - tjl * nt, tj = tj0 + tjl;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lc + 4 * r, col = 16 * tj + lr;
+                if (row < n && col < n) Uk[row + (size_t)col * n] = acc[m][r];
+              }
+            }
+          }
+        }
+        __syncthreads();      // (the block's writes of the new basis are visible to the block)
+        for (int j = wv; j < n; j += NW) {
+          double nr = 0.0;
+          for (int i = lane; i < n; i += 64) { const double v = Uk[i + (size_t)j * n]; V[i + (size_t)j * ldv] = v; nr += v * v; }
+          nr = wave_sum(nr);
+          if (lane == 0) nrm[j] = nr;
+        }
+        __syncthreads();
+      };
+      const double kcap = a.refine_kcap;
+      const double T = tolv * sqrt(fro2), accT = a.refine_acc * T;
+      int outcome = 2;      // 0: converged as it arrived, 1: one step, 2: on to the sweeps
+      double r2 = rdef * rdef, k2 = 0.0;
+      bool measured = false, far = true;
+      const bool do_gram = !a.rstate || gcred == 0 || !(rdef <= 0.03 * a.refine_acc * tolv);
+      RST(0)
+      if (do_gram) {
+        // lower tiles of G = V'V over 16-row chunks of V
+        d4_t g[kTilesPerWave];
+#pragma unroll
+        for (int m = 0; m < kTilesPerWave; ++m) g[m] = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int l0 = 0; l0 < n; l0 += 16) {
+          {
+            const int lv = tid & 15, l2 = l0 + lv;
+            for (int j = tid >> 4; j < 16 * nt; j += NT >> 4) Pn[lv * kPanelLd + j] = (l2 < n && j < n) ? V[l2 + (size_t)j * ldv] : 0.0;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int m = 0; m < kTilesPerWave; ++m)
+            if (tti[m] >= 0) {
+#pragma unroll
+              for (int k4 = 0; k4 < 4; ++k4) {
+                const int kx = 4 * k4 + lc;
+                g[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pn[kx * kPanelLd + 16 * tti[m] + lr], Pn[kx * kPanelLd + 16 * ttj[m] + lr], g[m], 0, 0, 0);
+              }
+            }
+          __syncthreads();
+        }
+        double rr2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < kTilesPerWave; ++m)
+          if (tti[m] >= 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * tti[m] + lc + 4 * r, j = 16 * ttj[m] + lr;
+              if (i < n && j < n) {
+                if (i == j) { const double v = 1.0 - g[m][r]; rr2 += v * v; }
+                else if (i > j) rr2 += 2.0 * g[m][r] * g[m][r];
+              }
+            }
+        r2 = uniform(block_sum(rr2, red));
+        measured = true;
+        const double rep = 0.01 * a.refine_acc * tolv;
+        if (r2 > rep * rep && r2 <= 0.01) {
+          // a defect worth removing: V <- V (I + R / 2) = V (3 I - G) / 2 (Newton-Schulz), then B = V'AV again from the matrix in HBM
+#pragma unroll
+          for (int m = 0; m < kTilesPerWave; ++m)
+            if (tti[m] >= 0)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = 16 * tti[m] + lc + 4 * r, col = 16 * ttj[m] + lr;
+                if (row < n && col < n) {
+                  const double v = (row == col ? 1.5 : 0.0) - 0.5 * g[m][r];
+                  Tk[(size_t)row * n + col] = v;
+                  if (tti[m] != ttj[m]) Tk[(size_t)col * n + row] = v;
+                }
+              }
+          __syncthreads();
+          apply_M();
+          for (int j = tid >> 6; j < npg; j += NT >> 6)
+            for (int i = (tid & 63) + j; i < npg; i += 64) {
+              double v = 0.0;
+              if (i < n && j < n) v = 0.5 * (nuk[(size_t)j * n + i] + nuk[(size_t)i * n + j]);
+              A[ixl(i, j)] = v;
+            }
+          __syncthreads();
+          pk_congruence();
+          r2 = r2 * r2;         // (the defect is squared by the step, up to a factor 3/8)
+        }
+      }
+      RST(1)
+      if (tid < npg) dvec[tid] = tid < n ? A[ixl(tid, tid)] : 0.0;
+      __syncthreads();
+      double off2 = 0.0, unpp = 0.0, unnn = 0.0, unx = 0.0, kd2 = 0.0, cpos = 0.0, cneg = 0.0;
+      {
+        double o2 = 0.0, q2 = 0.0, upp = 0.0, unn = 0.0, ux = 0.0, qd2 = 0.0;
+        for (int j = tid >> 6; j < n; j += NW)
+          for (int i = (tid & 63) + j + 1; i < n; i += 64) {
+            const double b = A[ixl(i, j)], di = dvec[i], dj = dvec[j], gap = dj - di;
+            o2 += 2.0 * b * b;
+            if (fabs(b) <= kcap * fabs(gap) && gap != 0.0) {
+              const double e = b * rcp_nr2(gap);
+              q2 += 2.0 * e * e;
+              qd2 += e * e * (dj * dj + di * di);
+            } else {
+              const double dd = di * dj;
+              if (b * b < dd) { if (di > 0.0) upp += 2.0 * b * b; else unn += 2.0 * b * b; }   // same sign, inertia kept
+              else ux += 2.0 * b * b;
+            }
+          }
+        off2 = uniform(block_sum(o2, red)); k2 = uniform(block_sum(q2, red)); unpp = uniform(block_sum(upp, red));
+        unnn = uniform(block_sum(unn, red)); unx = uniform(block_sum(ux, red)); kd2 = uniform(block_sum(qd2, red));
+        cpos = uniform(block_sum((tid < n && dvec[tid] > 0.0) ? 1.0 : 0.0, red));
+        cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
+        __syncthreads();
+      }
+      RST(2)
+      if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
+      else if (r2 <= 1e-4 && k2 <= 0.09) {
+        const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0) + sqrt(r2) * sqrt(fro2);   // (an uncorrected defect shows in the projection to first order)
+        const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);
+        const bool prefer_pos = cpos <= cneg;
+        if ((prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
+        else if ((prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
+        far = fmin(pred_pos, pred_neg) > 10.0 * accT;
+      }
+      if (side_force != 0) {
+        // K into the packed triangle (0 for the pairs first order cannot resolve)
+        for (int j = tid >> 6; j < n; j += NW)
+          for (int i = (tid & 63) + j + 1; i < n; i += 64) {
+            const double b = A[ixl(i, j)], gap = dvec[j] - dvec[i];
+            A[ixl(i, j)] = (fabs(b) <= kcap * fabs(gap) && gap != 0.0) ? b * rcp_nr2(gap) : 0.0;
+          }
+        __syncthreads();
+        auto Ks = [&](int i, int l) { return (i < n && l < n && i != l) ? (i > l ? A[ixl(i, l)] : -A[ixl(l, i)]) : 0.0; };
+        {
+          // column sums for the second-order eigenvalues: 4 lanes per column
+          const int col = tid >> 2, part = tid & 3;
+          double s1 = 0.0, s2 = 0.0;
+          if (col < n)
+            for (int kx = part; kx < n; kx += 4)
+              if (kx != col) { const double e = A[ixs(kx, col)]; s1 += e * e; s2 += e * e * dvec[kx]; }
+          s1 += dpp_row<0xB1>(s1); s1 += dpp_row<0x4E>(s1);
+          s2 += dpp_row<0xB1>(s2); s2 += dpp_row<0x4E>(s2);
+          if (part == 0 && col < n) { cs1[col] = s1; cs2[col] = s2; }
+        }
+        RST(3)
+        // K^2 (symmetric), lower tiles: both factors gathered from the packed triangle with their signs
+        d4_t sq[kTilesPerWave];
+#pragma unroll
+        for (int m = 0; m < kTilesPerWave; ++m) {
+          d4_t c = {0.0, 0.0, 0.0, 0.0};
+          if (tti[m] >= 0)
+            for (int kk = 0; kk < ks; ++kk) {
+              const int kx = 4 * kk + lc;
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(Ks(16 * tti[m] + lr, kx), Ks(kx, 16 * ttj[m] + lr), c, 0, 0, 0);
+            }
+          sq[m] = c;
+        }
+        // X = I + K + K^2 / 2 into the scratch (row-major, both triangles)
+#pragma unroll
+        for (int m = 0; m < kTilesPerWave; ++m)
+          if (tti[m] >= 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * tti[m] + lc + 4 * r, col = 16 * ttj[m] + lr;
+              if (row < n && col < n) {
+                const double kv = Ks(row, col), h = 0.5 * sq[m][r];
+                Tk[(size_t)row * n + col] = (row == col ? 1.0 : 0.0) + kv + h;
+                if (tti[m] != ttj[m]) Tk[(size_t)col * n + row] = h - kv;
+              }
+            }
+        __syncthreads();
+        RST(4)
+        apply_M();
+        RST(5)
+        if (tid < n) A[ixl(tid, tid)] = (dvec[tid] * (1.0 + cs1[tid]) - cs2[tid]) / nrm[tid];
+        __syncthreads();
+        outcome = 1;
+        refined = true;
+      }
+      if (tid == 0) {
+        if (a.stats) atomicAdd(&a.stats[4 + outcome], 1);
+        if (a.rstate) {
+          int word;
+          if (outcome == 2 && far) { const int lv = min(level + 1, 5); word = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }
+          else if (outcome == 2) word = (credit << 16) | (level << 8);
+          else word = min(credit + 1, 255) << 16;
+          double rnew = measured ? sqrt(r2) : rdef;
+          if (outcome == 1) rnew = rnew * (1.0 + 2.2 * sqrt(k2)) + 0.25 * k2 * k2;     // (no R term in this form: the defect is carried, every step adds |K|_F^4 / 4)
+          a.rstate[4 * k] = word | ((do_gram ? 3 : gcred - 1) << 24);
+          *reinterpret_cast<double*>(a.rstate + 4 * k + 2) = rnew;
+        }
+      }
+    } else if (warm && rmode != 0 && a.Ug && wait > 0 && tid == 0) {
       a.rstate[4 * k] = (gcred << 24) | (credit << 16) | (level << 8) | (wait - 1);
       if (a.stats) atomicAdd(&a.stats[7], 1);
     }
@@ -2023,9 +2298,11 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   }
 #ifdef NNSDP_STAMPS
   if (k == 0 && tid == 0 && a.eig) { long long* dbg = reinterpret_cast<long long*>(a.eig + 4096); dbg[69] = clock64() - dbg[68]; }
-  if (PK && k == 0 && tid == 0 && !a.eig)
+  if (PK && k == 0 && tid == 0 && !a.eig) {
+    if (rst[5]) printf("[stamps packed stage n=%d] Gram %lld analysis %lld K + sums %lld K^2 + X %lld V X + copy %lld\n", n, rst[1] - rst[0], rst[2] - rst[1], rst[3] - rst[2], rst[4] - rst[3], rst[5] - rst[4]);
     printf("[stamps packed n=%d] (last sweep: V update %lld) load %lld congruence %lld sweeps %lld (%d) select %lld reconstruct + stores %lld | total %lld\n", n, rst[16] - rst[15], sec_t[1] - sec_t[0], sec_t[2] - sec_t[1],
            sec_t[3] - sec_t[2], sweeps, rst[10] - sec_t[3], clock64() - rst[10], clock64() - sec_t[0]);
+  }
   if (PP && k == 0 && (tid == 0 || tid == NT - 64) && !a.eig) {
     const long long te = clock64();
     printf("[stamps n=%d wave %d] (load: to LDS %lld barrier %lld symmetrise %lld sum %lld) load %lld congruence %lld to-stage %lld | gram %lld diag %lld analyse %lld | E~ %lld sums %lld E~^2 %lld V-update %lld lambda %lld | to-select %lld select %lld W %lld V-store %lld | total %lld\n",

@@ -583,7 +583,7 @@ def test_packed_variant_blocks_129_to_160_warm_and_cold_against_lapack(n):
     for eta, tol in ((1e-3, 1e-6), (1e-6, 1e-9)):
         D = rng.standard_normal((n, n)); D = 0.5 * (D + D.T)
         A1 = A0 + eta * np.linalg.norm(A0) / np.linalg.norm(D) * D
-        W, V, oc, _ = na.project_psd_warm([A1], [Q], tol, refine=True)       # (the refinement stage lives in the ping-pong variant: ignored here)
+        W, V, oc, _ = na.project_psd_warm([A1], [Q], tol, refine=False)      # (the packed sweeps alone; the stage in its packed form: tests/test_refine_projection.py)
         w, U = np.linalg.eigh(A1)
         assert np.linalg.norm(W[0] - (U * np.maximum(w, 0)) @ U.T) <= tol * np.linalg.norm(A1)
         assert np.linalg.norm(V[0].T @ V[0] - np.eye(n)) <= 1e-10

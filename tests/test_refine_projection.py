@@ -181,6 +181,64 @@ def test_one_unresolvable_pair_across_zero_is_rotated_exactly(n, monkeypatch):
     assert np.linalg.norm(W0[0] - Wx) <= tol * np.linalg.norm(A1)
 
 
+@pytest.mark.parametrize("n", [129, 151, 160])
+@pytest.mark.parametrize("eta", [1e-4, 1e-6])
+def test_packed_variant_takes_the_refinement_step(n, eta):
+    """blocks 129 .. 160 (the reference's 151-wide cliques of width-50 networks): the stage in its packed form - antisymmetric K in the
+    packed triangle, X = I + K + K^2 / 2 and V X streamed through the LDS panel - takes the step on a slowly moving matrix and meets
+    the level it promises; the packed sweeps on the same input are the control"""
+    rng = np.random.default_rng(n)
+    spec = np.concatenate([np.linspace(0.2, 2.0, n // 2), -np.linspace(0.1, 1.5, n - n // 2)])
+    A0, Q0 = _sym(rng, n, spec)
+    A1 = _perturb(rng, A0, eta)
+    tol = 0.3 * eta
+    W, V, oc, _ = na.project_psd_warm([A1], [Q0], tol, refine=True)
+    Wx = oadmm.project_psd(A1)
+    assert oc == [0, 1, 0, 0, 0], oc
+    assert np.linalg.norm(W[0] - Wx) <= 30 * tol * np.linalg.norm(A1)
+    assert np.linalg.norm(V[0].T @ V[0] - np.eye(n)) <= 1e-3
+    Wj, Vj, ocj, _ = na.project_psd_warm([A1], [Q0], tol, refine=False)
+    assert ocj == [0, 0, 0, 0, 0]
+    assert np.linalg.norm(Wj[0] - Wx) <= tol * np.linalg.norm(A1)
+
+
+def test_packed_variant_persistent_basis_and_fall_back():
+    """the packed stage over 20 consecutive small moves with its state carried (Gram product on one visit in four), then a large move
+    that must go on to the sweeps, then a basis with a defect that the Gram visit has to remove (Newton-Schulz pass + congruence again)"""
+    rng = np.random.default_rng(5)
+    ns = [151, 106, 160]
+    mats, bases = [], []
+    for n in ns:
+        spec = np.concatenate([np.linspace(0.05, 2.0, n - n // 3), -np.linspace(0.05, 1.0, n // 3)])
+        A, Q = _sym(rng, n, spec)
+        mats.append(A)
+        bases.append(Q)
+    eta, tol = 3e-5, 1e-5
+    state = np.zeros(4 * len(ns), dtype=np.int32)
+    steps = 0
+    for it in range(20):
+        mats = [_perturb(rng, A, eta) for A in mats]
+        W, bases, oc, _ = na.project_psd_warm(mats, bases, tol, refine=True, state=state)
+        steps += oc[1]
+        for A, Wk, Vk in zip(mats, W, bases):
+            assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * tol * np.linalg.norm(A), it
+            assert np.linalg.norm(Vk.T @ Vk - np.eye(len(A))) <= 1e-6
+    assert steps >= 55
+    big = [_perturb(rng, A, 0.2) for A in mats]
+    W, V2, oc, _ = na.project_psd_warm(big, bases, 1e-7, refine=True)
+    assert oc[2] == len(ns), oc
+    for A, Wk in zip(big, W):
+        assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 1e-7 * np.linalg.norm(A) + 1e-12
+    bent = [Q @ (np.eye(len(Q)) + 1e-5 * rng.standard_normal(Q.shape)) for Q in bases]
+    mats = [_perturb(rng, A, 1e-6) for A in mats]
+    W, V3, oc, _ = na.project_psd_warm(mats, bent, 1e-6, refine=True)
+    for A, Wk, Vk, Qb in zip(mats, W, V3, bent):
+        assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * 1e-6 * np.linalg.norm(A)
+        before = np.linalg.norm(Qb.T @ Qb - np.eye(len(A)))
+        assert before >= 1e-3
+        assert np.linalg.norm(Vk.T @ Vk - np.eye(len(A))) <= before * before          # the pass squares the defect (3/8 R^2)
+
+
 def test_solver_with_and_without_refinement_agree():
     """a whole solve: same optimum, the refinement stage carries most block visits late in the solve"""
     q = helpers.product_query(helpers.load_problem("W40-D20", 0))
