@@ -84,10 +84,15 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // projection kernel variant for a launch whose largest block is nmax.  Default: ping-pong odd-even sweeps for
 // 41..96, register-resident systolic sweeps for 97..128, LDS round robin for small blocks.
 // Diagnostic overrides: NNSDP_PROJ_ALG=0/1/2/3, NNSDP_BLOCK=1.
-static int proj_algorithm(int nmax) {
+// warm_refine: the launches are a solver's warm iterations with the refinement stage on.  Blocks 97 .. 128 then take the packed variant as
+// well: its stage carries most of a solve (width-50 networks in the Path decomposition, 101-wide blocks: 565 -> 347 us per iteration,
+// tools/width50_variants.py), while the systolic variant - faster sweeps, no stage - stays the choice for cold one-off projections.
+static int proj_algorithm(int nmax, bool warm_refine = false) {
   if (nnsdp::proj_packed_ok(nmax)) return nnsdp::kProjPacked;      // 129 .. 160: packed lower triangle in LDS (the only variant that fits)
+  if (warm_refine && nmax > 96 && nmax <= 128 && !std::getenv("NNSDP_PROJ_ALG")) return nnsdp::kProjPacked;
   int alg = nnsdp::proj_pp_ok(nmax) ? nnsdp::kProjPingPong : (nnsdp::proj_sys_ok(nmax) ? nnsdp::kProjSystolic : nnsdp::kProjRoundRobin);
   if (const char* e = std::getenv("NNSDP_PROJ_ALG")) alg = std::atoi(e);
+  if (alg == nnsdp::kProjPacked && nmax > 96 && nmax <= nnsdp::kMaxLdsBlock) return alg;      // (diagnostic: the packed variant for 97 .. 128 as well)
   if (const char* e = std::getenv("NNSDP_BLOCK")) { if (std::atoi(e) != 0) alg = nnsdp::kProjBlock; }
   if (alg == nnsdp::kProjSystolic && !nnsdp::proj_sys_ok(nmax)) alg = nnsdp::kProjRoundRobin;
   if (alg == nnsdp::kProjBlock && !nnsdp::proj_block_ok(nmax)) alg = nnsdp::kProjRoundRobin;
@@ -436,7 +441,8 @@ struct nnsdp_solver {
       big_info.alloc(big_idx.size()); big_info.zero();
     }
     const int nsm = std::max(nmax_small, 1);
-    proj_alg = proj_algorithm(nsm);
+    if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // (diagnostic override, read before the variant is chosen)
+    proj_alg = proj_algorithm(nsm, opt.proj_refine != 0);
     v_lds = proj_alg != nnsdp::kProjPacked && proj_lds_bytes(nsm, true, proj_alg) <= 160 * 1024;
     lds_bytes = proj_lds_bytes(nsm, v_lds, proj_alg);
     // gather sources: entry e <- (clique k, lower element (i,j))
@@ -1475,7 +1481,7 @@ struct nnsdp_batch {
     }
     nblocks = (int)map.size();
     nmax = std::max(nmax, 1);
-    alg = proj_algorithm(nmax);
+    alg = proj_algorithm(nmax, !act.empty() && act[0]->opt.proj_refine != 0);
     if (alg == nnsdp::kProjPacked)          // one launch for all members in the packed variant: every member needs its warm-start scratch
       for (size_t b = 0; b < act.size(); ++b) {
         if (!act[b]->Tg.p) { act[b]->Tg.alloc(act[b]->nmat); act[b]->Tg.zero(); pw[b].Tg = pc[b].Tg = act[b]->Tg.p; }
