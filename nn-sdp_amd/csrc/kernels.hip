@@ -1244,10 +1244,12 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         }
       }
       RST(1)
-      if (tid < npg) dvec[tid] = tid < n ? A[ixl(tid, tid)] : 0.0;
-      __syncthreads();
-      double off2 = 0.0, unpp = 0.0, unnn = 0.0, unx = 0.0, kd2 = 0.0, cpos = 0.0, cneg = 0.0;
-      {
+      double off2 = 0.0, unpp = 0.0, unnn = 0.0, unx = 0.0, kd2 = 0.0, cpos = 0.0, cneg = 0.0, pred0 = 0.0;
+      // analysis of all pairs (nothing is written: a rejected block reaches the sweeps untouched) and the decision, as in the
+      // ping-pong form
+      auto pk_analyse = [&]() {
+        if (tid < npg) dvec[tid] = tid < n ? A[ixl(tid, tid)] : 0.0;
+        __syncthreads();
         double o2 = 0.0, q2 = 0.0, upp = 0.0, unn = 0.0, ux = 0.0, qd2 = 0.0;
         for (int j = tid >> 6; j < n; j += NW)
           for (int i = (tid & 63) + j + 1; i < n; i += 64) {
@@ -1268,16 +1270,63 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         cpos = uniform(block_sum((tid < n && dvec[tid] > 0.0) ? 1.0 : 0.0, red));
         cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
         __syncthreads();
-      }
+        if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
+        else if (r2 <= 1e-4 && k2 <= 0.09) {
+          pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0) + sqrt(r2) * sqrt(fro2);   // (an uncorrected defect shows in the projection to first order)
+          const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);
+          const bool prefer_pos = cpos <= cneg;
+          if ((prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
+          else if ((prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
+          far = fmin(pred_pos, pred_neg) > 10.0 * accT;
+        }
+      };
+      pk_analyse();
       RST(2)
-      if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
-      else if (r2 <= 1e-4 && k2 <= 0.09) {
-        const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0) + sqrt(r2) * sqrt(fro2);   // (an uncorrected defect shows in the projection to first order)
-        const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);
-        const bool prefer_pos = cpos <= cneg;
-        if ((prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
-        else if ((prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
-        far = fmin(pred_pos, pred_neg) > 10.0 * accT;
+      // the one pair across zero that first order cannot resolve (see the ping-pong form): rotated exactly - its two rows of the packed
+      // B, its two columns of V in HBM - and the block analysed again, at most refine_pivots times
+      int pivots = 0;
+      if (__builtin_expect(!refined && side_force == 0 && r2 <= 1e-4 && k2 <= 0.09 && unx > 0.0 && a.refine_pivots > 0, 0)) {
+        for (;;) {
+          double pm = 0.0;
+          int pidx = 0;
+          for (int j = tid >> 6; j < n; j += NW)
+            for (int i = (tid & 63) + j + 1; i < n; i += 64) {
+              const double b = A[ixl(i, j)], di = dvec[i], dj = dvec[j], gap = dj - di;
+              if (!(fabs(b) <= kcap * fabs(gap) && gap != 0.0) && !(b * b < di * dj) && b * b > pm) { pm = b * b; pidx = (i << 8) | j; }
+            }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(pm, o, 64);
+            const int oi = __shfl_xor(pidx, o, 64);
+            if (om > pm || (om == pm && oi > pidx)) { pm = om; pidx = oi; }
+          }
+          if (lane == 0) { cs1[wv] = pm; cs2[wv] = (double)pidx; }
+          __syncthreads();
+          pm = 0.0; pidx = 0;
+          for (int w_ = 0; w_ < NW; ++w_) { const double om = cs1[w_]; const int oi = (int)cs2[w_]; if (om > pm || (om == pm && oi > pidx)) { pm = om; pidx = oi; } }
+          pm = uniform(pm); pidx = __builtin_amdgcn_readfirstlane(pidx);
+          if (!(pm > 0.0) || !(pred0 + sqrt(fmax(fmin(unpp, unnn) + unx - 2.0 * pm, 0.0)) <= accT)) break;     // (uniform)
+          const int p_ = pidx >> 8, q_ = pidx & 255;       // p_ > q_
+          const double bpp = A[ixl(p_, p_)], bqq = A[ixl(q_, q_)], bpq = A[ixl(p_, q_)];
+          const double tau = (bqq - bpp) / (2.0 * bpq);
+          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double cc = 1.0 / sqrt(1.0 + tt * tt), ss = tt * cc;
+          __syncthreads();
+          if (tid < n) {
+            if (tid != p_ && tid != q_) {
+              double* xp = A + ixs(tid, p_);
+              double* xq = A + ixs(tid, q_);
+              const double x = *xp, y = *xq; *xp = cc * x - ss * y; *xq = ss * x + cc * y;
+            } else if (tid == p_) { A[ixl(p_, p_)] = bpp - tt * bpq; A[ixl(q_, q_)] = bqq + tt * bpq; A[ixl(p_, q_)] = 0.0; }
+          } else if (tid >= 256 && tid < 256 + n) {
+            double* vp = V + (tid - 256) + (size_t)p_ * ldv; double* vq = V + (tid - 256) + (size_t)q_ * ldv;
+            const double x = *vp, y = *vq; *vp = cc * x - ss * y; *vq = ss * x + cc * y;
+          }
+          __syncthreads();
+          ++pivots;
+          pk_analyse();
+          if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= 0.09) || !(unx > 0.0)) break;
+        }
       }
       if (side_force != 0) {
         // K into the packed triangle (0 for the pairs first order cannot resolve)
@@ -1335,7 +1384,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         refined = true;
       }
       if (tid == 0) {
-        if (a.stats) atomicAdd(&a.stats[4 + outcome], 1);
+        if (a.stats) { atomicAdd(&a.stats[4 + outcome], 1); if (pivots) atomicAdd(&a.stats[outcome == 1 ? 12 : 13], pivots); }
         if (a.rstate) {
           int word;
           if (outcome == 2 && far) { const int lv = min(level + 1, 5); word = (lv << 8) | (lv >= 2 ? (1 << (lv - 1)) : 0); }

@@ -151,7 +151,7 @@ def test_gram_product_is_skipped_three_visits_in_four_and_the_defect_estimate_ho
     assert credits[1] == [2, 2, 2] and credits[2] == [1, 1, 1] and credits[3] == [0, 0, 0] and credits[4] == [3, 3, 3]
 
 
-@pytest.mark.parametrize("n", [57, 85])
+@pytest.mark.parametrize("n", [57, 85, 151])
 def test_one_unresolvable_pair_across_zero_is_rotated_exactly(n, monkeypatch):
     """the late-solve rejection: ONE pair of eigenvalues on either side of zero whose coupling is far above their gap (first order cannot
     resolve it, and it counts whichever side the projection is rebuilt from).  The stage rotates that pair exactly and takes its step;
