@@ -132,6 +132,8 @@ def main():
                          "(strong; the replica figure is reported beside it); replica = one independent SDP per GPU only (weak)")
     ap.add_argument("--batch", type=int, default=13, help="independent SDPs solved side by side in the batched leg (0/1 = skip)")
     ap.add_argument("--cert-seconds", type=float, default=30.0, help="time cap of the time-to-certificate solve (0 = skip)")
+    ap.add_argument("--wide-burn-in", type=int, default=8000,
+                    help="iterations before the timed window of the wide-block leg (ACAS-Xu shaped network, the reference's 151-wide cliques; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -351,6 +353,31 @@ def main():
                           "eig_frac_of_fp64_peak_if_same_share": agg * float(sm["eig_flops_per_iter"]) / 1e12 / FP64_PEAK_TFLOPS,
                           "note": "independent SDPs (beta sweep of experiments/scale.jl:28, hyperplanes of findReach2Dpoly, ACAS sub-queries) in lockstep on one GPU, "
                                   "nnsdp_batch_*: one launch per stage for all SDPs, hipGraph replay; 13 x 19 blocks = 247 of the 256 CUs"}
+    if rank == 0 and world == 1 and args.wide_burn_in > 0 and not shard:
+        # BASELINE config 5's shape on ONE GPU: an ACAS-Xu shaped network (5-50x6-5, random weights), reach-hyperplane query, plain interval
+        # arithmetic (no neuron stable), the reference's Single cliques = 106 + 4 x 151: the packed-triangle variant of the projection kernel
+        from nnsdp_amd import frontend as F
+        netw = na.randomNetwork([5] + [50] * 6 + [5], seed=1234)
+        x0 = np.full(5, 0.3)
+        lo, hi = x0 - 0.05, x0 + 0.05
+        xi, acx = F.intervalsWorstCase(lo, hi, netw)
+        nrm = np.zeros(5); nrm[0] = 1.0
+        qw = na.ReachQuery(ffnet=netw, qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_reach=na.QcReachHplane(normal=nrm),
+                           qc_activs=F.makeQcActivsIntvs(netw, xi, acx, 0))
+        sw = na.Solver(qw, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9))
+        sw.advance(args.wide_burn_in)
+        sw.iterate(16, time_eig=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        msw = sw.iterate(200, time_eig=True)
+        torch.cuda.synchronize()
+        dtw = time.perf_counter() - t1
+        smw = sw.finish().summary
+        sw.close()
+        out["wide_blocks"] = {"workload": "ACAS-Xu shaped 5-50x6-5 (random weights), reach hyperplane, interval arithmetic, SingleDecomp",
+                              "blocks": smw["n_cliques"], "max_block": smw["max_clique"], "burn_in_iters": args.wide_burn_in, "steps": 200,
+                              "iters_per_s": 200 / dtw, "kernel_avg_us": 1e3 * msw / 200, "refine_blocks": smw["refine_blocks"],
+                              "note": "one GPU, eager launches with per-launch events like `value`; not BASELINE's metric config"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         need = None
         if "time_to_cert" in out:
