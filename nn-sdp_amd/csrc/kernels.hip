@@ -2157,7 +2157,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           for (int rr = 0; rr < r1; ++rr) {
             // (requesting the operands of the thread's three pairs together before writing any - one LDS round trip per round - costs 13
             // spilled VGPRs and is slower, 1.58 M against 1.44 M cycles per sweep; one pair through FOUR rows per thread - a third fewer LDS
-            // bytes per row rotation - is slower too, 1.08 against 1.02 ms per warm launch: the four rows of a thread collide in the banks)
+            // bytes per row rotation - is slower too, 1.08 against 1.02 ms per warm launch, and so are two rows per thread, 1.12: only the layout with
+            // the 32 rows of the panel across the lanes is free of bank conflicts)
             for (int slot = stream; slot < half; slot += NT >> 5) {
               const int pq = pqs[rr * half + slot];
               if (pq >= 0) {                  // (padded index: the rotation is the identity)
