@@ -10,6 +10,9 @@
 //   gidx int32 [sum_k n_k^2]   pattern entry of every clique-matrix element, bit 31 = diagonal
 //   CSR (rows = pattern entries) and CSC (columns = multipliers) of the generator table A
 //   Minv [ng x ng]             inverse of M = I + A' D^-1 A (symmetric), the Woodbury core
+//   rstate int32 [4 x blocks]  refinement stage per block: back-off word (incl. the credit of visits without a Gram product) and the
+//                              running estimate of the eigenbasis' defect |I - V'V|_F
+//   Tg, Ug [sum_k n_k^2]       scratch of the packed variant (blocks 97 .. 160): warm-start product / rotation log / X, and the new basis
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
