@@ -112,18 +112,20 @@ def test_hip_solver_lands_on_the_independent_interior_point_optimum(name, beta):
     assert all(g["rho"] < p for p in g["published"])
 
 
-def test_deep_row_sits_inside_the_interior_point_bracket():
-    """a DEEP published row through the independent interior point: W10-D30 beta = 0, Zdim 303.  The method does not
+@pytest.mark.parametrize("name,within,above", [("W10-D30", 3e-4, 4e-3), ("W10-D20", 3e-4, 1e-4)])
+def test_deep_row_sits_inside_the_interior_point_bracket(name, within, above):
+    """DEEP published rows through the independent interior point: W10-D30 beta = 0, Zdim 303, and W10-D20 (Zdim 203:
+    299 iterations, gap 2.5e-7, dual feasible to 1.5e-14, lower bound 1.3463120 with the published values 6e-4 above it).  W10-D30:  The method does not
     converge to 1e-9 there (no Slater point; it stops with a numerical error after 814 iterations at a relative gap of 2e-6), but its dual
     iterate is feasible to 1.5e-12, so its dual objective IS a lower bound of the optimum of the reference's LMI
     (tests/golden/ipm_unconverged.json, profiles/r03_ipm_trace_W10-D30_b0.csv).  Our certified rho - a feasible point, an upper bound - is
     within 3e-4 of that lower bound: the optimum is enclosed, and the three published values lie more than 4e-3 above the enclosure."""
     import json
-    g = json.load(open(os.path.join(helpers.GOLDEN, "ipm_unconverged.json")))["W10-D30_b0"]
+    g = json.load(open(os.path.join(helpers.GOLDEN, "ipm_unconverged.json")))[f"{name}_b0"]
     assert g["dinf"] <= 1e-10 and g["gap"] <= 1e-5
-    q, s = _solve_all()[("W10-D30", 0)]
+    q, s = _solve_all()[(name, 0)]
     rho = s.objective_value
     assert g["lower"] * (1 - 1e-6) <= rho, (g["lower"], rho)
-    assert rho - g["lower"] <= 3e-4 * rho, (g["lower"], rho)
+    assert rho - g["lower"] <= within * rho, (g["lower"], rho)
     assert abs(s.summary["objective_admm"] - g["rho"]) <= 1e-4 * rho          # the ADMM iterate and the interior point's primal iterate
-    assert min(g["published"]) >= rho * (1 + 4e-3)
+    assert min(g["published"]) >= rho * (1 + above), (min(g["published"]), rho)
