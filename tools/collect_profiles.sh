@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BURN=2000; WARM=50; STEPS=200; LATE=18000
-ARGS="--steps $STEPS --warmup $WARM --burn-in $BURN --late-burn-in $LATE --batch 0 --no-cpu-baseline --cert-seconds 0"
+ARGS="--steps $STEPS --warmup $WARM --burn-in $BURN --late-burn-in $LATE --batch 0 --no-cpu-baseline --cert-seconds 0 --wide-burn-in 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_$C.err
