@@ -1,6 +1,6 @@
 """(diagnostic) cycle stamps of the refinement path of the projection kernel, block 0 of a launch, from a -DNNSDP_STAMPS build of the
 library that is never shipped:
-    hipcc -O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -DNNSDP_STAMPS nn-sdp_amd/csrc/api.hip -o nn-sdp_amd/nnsdp_amd/libnnsdp_hip_stamps.so -lrocsolver -lrocblas -ldl
+    hipcc -O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -pthread -DNNSDP_STAMPS nn-sdp_amd/csrc/api.hip -o nn-sdp_amd/nnsdp_amd/libnnsdp_hip_stamps.so -lrocsolver -lrocblas -ldl
 usage: python tools/refine_stamps.py [n=85] [blocks=19]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
