@@ -313,7 +313,7 @@ struct nnsdp_solver {
   // device state
   DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate;
   double refine_acc = 30.0, refine_kcap = 0.05, refine_loose = 1.0;
-  int refine_pivots = 2;
+  int refine_pivots = 2, gram_credit = 3;
   int nlong = 0;
   DBuf<long long> d_coff, d_soff;
   DBuf<unsigned char> d_isdiag;
@@ -481,6 +481,7 @@ struct nnsdp_solver {
     if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) refine_kcap = std::atof(e);
     if (const char* e = std::getenv("NNSDP_REFINE_LOOSE")) refine_loose = std::atof(e);
     if (const char* e = std::getenv("NNSDP_REFINE_PIVOTS")) refine_pivots = std::atoi(e);
+    if (const char* e = std::getenv("NNSDP_GRAM_EVERY")) gram_credit = std::min(std::max(std::atoi(e) - 1, 0), 15);
     {
       std::vector<int> lr;
       for (int e = 0; e < S.NE; ++e)
@@ -789,7 +790,7 @@ struct nnsdp_solver {
     a.warm = warm ? 1 : 0;
     a.max_sweeps = 15;
     a.tol = kProjTol;
-    a.refine = opt.proj_refine; a.rstate = d_rstate.p + 4 * k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_pivots = refine_pivots;
+    a.refine = opt.proj_refine; a.rstate = d_rstate.p + 4 * k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_pivots = refine_pivots; a.gram_credit = gram_credit;
     if (big_idx.empty()) {
       if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
       return;
@@ -1458,7 +1459,7 @@ struct nnsdp_batch {
       q.nu = s->nu.p + s->S.ng; q.w = s->w.p + s->S.ng; q.Vg = s->Vg.p; q.eig = nullptr; q.Tg = s->Tg.p; q.Ug = s->Ug.p;
       q.kappa = s->d_kappa(); q.tol_dev = s->scal.p + 2; q.stats = s->d_stats.p;
       q.max_sweeps = 15; q.tol = nnsdp_solver::kProjTol;
-      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap; q.refine_loose = s->refine_loose; q.refine_pivots = s->refine_pivots;
+      q.refine = s->opt.proj_refine; q.rstate = s->d_rstate.p; q.refine_acc = s->refine_acc; q.refine_kcap = s->refine_kcap; q.refine_loose = s->refine_loose; q.refine_pivots = s->refine_pivots; q.gram_credit = s->gram_credit;
       q.warm = 1; pw.push_back(q);
       q.warm = 0; pc.push_back(q);
       // blocks up to 128 of every SDP share ONE launch of the LDS-resident kernel; blocks above (the reference's 151-wide cliques of
@@ -2030,7 +2031,7 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   ProjArgs a{};
   a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p; a.Ug = dU.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
-  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0; a.refine_pivots = 2;
+  a.refine = refine; a.rstate = drs.p; a.refine_acc = 30.0; a.refine_kcap = 0.05; a.refine_loose = 1.0; a.refine_pivots = 2; a.gram_credit = 3;
   if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);
   if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) a.refine_kcap = std::atof(e);
   if (const char* e = std::getenv("NNSDP_REFINE_PIVOTS")) a.refine_pivots = std::atoi(e);

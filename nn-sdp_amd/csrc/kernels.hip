@@ -109,6 +109,7 @@ struct ProjArgs {
                           // iterations still to skip, [2..3] = estimate of |I - V'V|_F as a double; zero-initialised (may be null)
   double refine_acc;      // a refinement step is accepted without a check when its PREDICTED off(A) is below refine_acc x tol |A|
   double refine_kcap;     // pairs whose first-order rotation angle B_ij / (d_j - d_i) exceeds this are left to the sweeps
+  int gram_credit;        // visits a block may run without the Gram product after a visit that measured it (0 .. 15)
   int refine_pivots;      // exact rotations of the dominant pair first order cannot resolve, per visit (0 = off)
   double refine_loose;    // >= 1: the one-off acceptance level of an isolated near miss, as a multiple of refine_acc (1 = off)
   int max_sweeps;
@@ -1075,7 +1076,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           // carried; every step adds its |K|_F^4 / 4
           double rnew = measured ? sqrt(r2) : rdef;
           if (outcome == 1) rnew = (do_gram ? r2 + 2.0 * sqrt(r2 * k2) : rdef * (1.0 + 2.2 * sqrt(k2))) + 0.25 * k2 * k2;     // ((I + X)'R(I + X) of an uncorrected R)
-          a.rstate[4 * k] = word | ((do_gram ? 3 : gcred - 1) << 24);
+          a.rstate[4 * k] = word | ((do_gram ? a.gram_credit : gcred - 1) << 24);
           *reinterpret_cast<double*>(a.rstate + 4 * k + 2) = rnew;
         }
       }
@@ -1395,7 +1396,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           else word = min(credit + 1, 255) << 16;
           double rnew = measured ? sqrt(r2) : rdef;
           if (outcome == 1) rnew = rnew * (1.0 + 2.2 * sqrt(k2)) + 0.25 * k2 * k2;     // (no R term in this form: the defect is carried, every step adds |K|_F^4 / 4)
-          a.rstate[4 * k] = word | ((do_gram ? 3 : gcred - 1) << 24);
+          a.rstate[4 * k] = word | ((do_gram ? a.gram_credit : gcred - 1) << 24);
           *reinterpret_cast<double*>(a.rstate + 4 * k + 2) = rnew;
         }
       }
