@@ -102,9 +102,10 @@ typedef struct nnsdp_options {
                              per iteration), 2 = structured (block-banded by network layer + low rank: two-level domain
                              decomposition, three launches, O(ng b) bytes), 0 = auto (structured from 3500 kept multipliers on,
                              when the generator table has that structure) */
-  int32_t proj_refine;    /* 1 (default): warm PSD blocks up to 96 first try the GEMM-only refinement of the eigenbasis kept from the
+  int32_t proj_refine;    /* 1 (default): warm PSD blocks of 41 .. 160 first try the GEMM-only refinement of the eigenbasis kept from the
                              previous iteration (one rotation of all pairs to second order on the matrix cores, accepted when its predicted
-                             off(A) is below 30 x the projection tolerance) and fall back to the exact Jacobi sweeps; 2: blocks whose
+                             off(A) is below 30 x the projection tolerance) and fall back to the exact Jacobi sweeps - up to 96 with the
+                             basis in LDS, 97 .. 160 in the packed-triangle variant with the basis in HBM; 2: blocks up to 96 whose
                              prediction misses by less than 30 x also take the step and are checked (B rebuilt, off(A) measured) before
                              the sweeps - measured: no gain on W40-D20; 0: sweeps only */
 } nnsdp_options;
