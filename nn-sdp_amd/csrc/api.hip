@@ -16,6 +16,7 @@
 
 #include "../../include/nnsdp.h"
 #include "kernels.hip"
+#include "refine_pipe.hpp"
 #include "setup.hpp"
 #include "minv.hpp"
 #include "intervals.hpp"
@@ -336,6 +337,15 @@ struct nnsdp_solver {
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   int graph_iters = 0;
+  bool graph_pipe = false;              // the captured iterations contain the tile-parallel pipeline
+  // tile-parallel form of the refinement stage (refine_pipe.hpp): five short launches over the whole chip in front of the one-CU kernel.
+  // pipe_mode 0: never, 1 (default): switched on / off at check iterations from the share of block visits the stage carries (the first
+  // ~2 000 iterations of a solve run the exact sweeps: the pipeline's launches would be pure overhead there), 2: always (diagnostic)
+  nnsdp::RefinePipe pipe;
+  int pipe_mode = 1;
+  bool pipe_on = false;
+  long long pipe_seen[2] = {0, 0};      // stats counters at the last check: visits carried by the stage / all warm visits
+  int stats_host[14];
   std::vector<hipEvent_t> ev;
   std::unique_ptr<RocHandle> roc;
   long long iters_done = 0, next_adapt = 0, next_trace = 0, next_cert = 500, best_iter = 0;
@@ -475,6 +485,8 @@ struct nnsdp_solver {
     d_isdiag.upload(isdiag); d_gidx.upload(gidx);
     lap("gather tables + upload");
     d_stats.alloc(14); d_stats.zero();
+    for (int& v : stats_host) v = 0;
+    if (const char* e = std::getenv("NNSDP_PIPE")) pipe_mode = std::atoi(e);                             // (diagnostic override)
     d_rstate.alloc(4 * (size_t)std::max(ncl, 1)); d_rstate.zero();      // (4 ints per block: kernels.hip, ProjArgs::rstate)
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // diagnostic overrides
     if (const char* e = std::getenv("NNSDP_REFINE_ACC")) refine_acc = std::atof(e);
@@ -545,6 +557,7 @@ struct nnsdp_solver {
     HIPCHK(hipMemcpy(scal.p, sc, sizeof(sc), hipMemcpyHostToDevice));
     if (lds_bytes > 64 * 1024) HIPCHK(proj_allow_big_lds());
     k0 = 0; k1 = ncl;
+    build_pipe();
     lap("state buffers");
     t_setup = now_s() - t_create0;
   }
@@ -700,6 +713,7 @@ struct nnsdp_solver {
     std::vector<int> start = shard_ranges(cn, nr);
     k0 = start[rk]; k1 = start[rk + 1];
     if (!big_idx.empty()) build_compact_lists(k0, k1);      // blocks above 128 (library path) are sharded like the others
+    build_pipe();                                           // (the tile-parallel pipeline works on the rank's own blocks)
     // source lists restricted to the owned cliques
     std::vector<int> sp = d_sptr.download();
     std::vector<long long> so = d_soff.download();
@@ -782,6 +796,20 @@ struct nnsdp_solver {
   }
   bool lead() const { return !sharded || rank == 0; }
 
+  // scratch and workgroup map of the tile-parallel pipeline for the blocks THIS process projects in one launch of the one-CU kernel
+  // (all of them, the rank's range in clique-sharded mode, or the compacted list beside library-path blocks)
+  void build_pipe() {
+    pipe.release();
+    pipe_on = false;
+    if (pipe_mode == 0 || opt.proj_refine != 1 || opt.warm_start == 0) return;
+    if (proj_alg != nnsdp::kProjPingPong && proj_alg != nnsdp::kProjPacked) return;      // (the variants whose kernel has the stage: 41 .. 160)
+    std::vector<int> lst;
+    if (big_idx.empty()) lst.assign(cn.begin() + k0, cn.begin() + k1);
+    else for (int k : proj_small) lst.push_back(cn[k]);
+    if (lst.empty()) return;
+    HIPCHK(pipe.build(lst.data(), (int)lst.size(), nmat));
+    pipe_on = pipe.ready && pipe_mode == 2;
+  }
   void enqueue_proj(bool warm) {
     ProjArgs a{};
     a.cn = d_cn.p + k0; a.coff = d_coff.p + k0; a.eoff = nullptr;
@@ -791,12 +819,17 @@ struct nnsdp_solver {
     a.max_sweeps = 15;
     a.tol = kProjTol;
     a.refine = opt.proj_refine; a.rstate = d_rstate.p + 4 * k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_pivots = refine_pivots; a.gram_credit = gram_credit;
+    const bool use_pipe = warm && pipe_on && pipe.ready;
     if (big_idx.empty()) {
-      if (k1 > k0) nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
+      if (k1 > k0) {
+        if (use_pipe) { pipe.launch(pipe.args(a), st); a.pmode = pipe.pmode; }
+        nnsdp::launch_proj(a, k1 - k0, nmax, v_lds, lds_bytes, st, proj_alg);
+      }
       return;
     }
     if (!proj_small.empty()) {
       a.cn = d_cn_s.p; a.coff = d_coff_s.p; a.rstate = d_rstate.p;      // (compacted block list: the first proj_small.size() slots)
+      if (use_pipe) { pipe.launch(pipe.args(a), st); a.pmode = pipe.pmode; }
       nnsdp::launch_proj(a, (int)proj_small.size(), nmax_small, v_lds, lds_bytes, st, proj_alg);
     }
     enqueue_big_blocks(st);
@@ -891,7 +924,7 @@ struct nnsdp_solver {
   }
 
   void build_graph(int n_iters) {
-    if (gexec && graph_iters == n_iters) return;
+    if (gexec && graph_iters == n_iters && graph_pipe == pipe_on) return;
     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
     if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -899,6 +932,7 @@ struct nnsdp_solver {
     HIPCHK(hipStreamEndCapture(st, &graph));
     HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     graph_iters = n_iters;
+    graph_pipe = pipe_on;
   }
 
   // run n plain iterations; timed=true launches eagerly with HIP events around the projection kernel
@@ -942,11 +976,24 @@ struct nnsdp_solver {
     enqueue_iteration(true, next_is_warm());
     ++iters_done;
     HIPCHK(hipMemcpyAsync(acc_host, acc.p, sizeof(acc_host), hipMemcpyDeviceToHost, st));
+    if (pipe.ready && pipe_mode == 1) HIPCHK(hipMemcpyAsync(stats_host, d_stats.p, sizeof(stats_host), hipMemcpyDeviceToHost, st));
   }
   void check_finish() {
     HIPCHK(hipStreamSynchronize(st));
     if (!big_idx.empty())     // rocSOLVER's convergence report of the library eigensolves since the last check
       for (rocblas_int v : big_info.download()) big_fail = big_fail || v != 0;
+    if (pipe.ready && pipe_mode == 1) {
+      // the pipeline pays once the stage carries the block visits (late phase); while the sweeps run it is five empty launches per
+      // iteration.  Decided from the counters of the window since the last check (deterministic: no timing enters), with hysteresis.
+      const long long carried = (long long)stats_host[4] + stats_host[5] + stats_host[8];
+      const long long all = carried + stats_host[6] + stats_host[7];
+      const long long dc = carried - pipe_seen[0], da = all - pipe_seen[1];
+      pipe_seen[0] = carried; pipe_seen[1] = all;
+      if (da > 0) {
+        if (!pipe_on && 10 * dc >= 7 * da) pipe_on = true;
+        else if (pipe_on && 10 * dc < 4 * da) pipe_on = false;
+      }
+    }
     const double* a = acc_host;
     double z0n = 0;  // |z0| (scaled) is 1 when normalised; compute anyway
     for (double v : S.z0) z0n += v * v;
@@ -2024,10 +2071,16 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   if (state) HIPCHK(hipMemcpy(drs.p, state, 4 * (size_t)batch * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dnu.p, mats, tot * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dV.p, basis, tot * sizeof(double), hipMemcpyHostToDevice));
-  const int alg = proj_algorithm(nmax);
-  bool v_lds = proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
+  // refine = 4: the tile-parallel pipeline (refine_pipe.hpp) in front of the kernel, as a solver runs it late in a solve; the kernel
+  // behind it (refine = 1) takes the blocks the pipeline leaves
+  const bool use_pipe = refine == 4;
+  if (use_pipe) refine = 1;
+  const int alg = proj_algorithm(nmax, refine != 0);      // (97 .. 128 with the stage on: the packed variant, as in a solver's warm iterations)
+  bool v_lds = alg != nnsdp::kProjPacked && proj_lds_bytes(nmax, true, alg) <= 160 * 1024;
   size_t lds = proj_lds_bytes(nmax, v_lds, alg);
   if (lds > 64 * 1024) HIPCHK(proj_allow_big_lds());
+  nnsdp::RefinePipe pp;
+  if (use_pipe) HIPCHK(pp.build(cn.data(), batch, tot));
   ProjArgs a{};
   a.cn = dcn.p; a.coff = dco.p; a.eoff = nullptr; a.nu = dnu.p; a.w = dw.p; a.Vg = dV.p; a.eig = nullptr; a.Tg = dT.p; a.Ug = dU.p;
   a.kappa = nullptr; a.tol_dev = nullptr; a.stats = dst.p; a.warm = 1; a.max_sweeps = 30; a.tol = tol;
@@ -2041,6 +2094,17 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   } ev;
   HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
   HIPCHK(hipEventRecord(ev.e0, nullptr));
+#ifdef NNSDP_STAMPS
+  DBuf<long long> ddbg;
+  if (use_pipe && pp.ready) { ddbg.alloc(5 * (size_t)pp.nwg * 8); ddbg.zero(); }
+#endif
+  if (use_pipe && pp.ready) {
+    nnsdp::PipeArgs pa = pp.args(a);
+#ifdef NNSDP_STAMPS
+    pa.dbg = ddbg.p;
+#endif
+    pp.launch(pa, nullptr); a.pmode = pp.pmode;
+  }
   launch_proj(a, batch, nmax, v_lds, lds, nullptr, alg);
   HIPCHK(hipEventRecord(ev.e1, nullptr));
   HIPCHK(hipGetLastError());
@@ -2048,6 +2112,29 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   if (kernel_ms) *kernel_ms = ms;
+#ifdef NNSDP_STAMPS
+  if (use_pipe && pp.ready) {
+    // (diagnostic build) wall-clock stamps (100 MHz) of the stamping wave of every workgroup: spans and phase averages per kernel
+    std::vector<long long> h = ddbg.download();
+    const char* names[5] = {"T", "B", "X", "V", "W"};
+    long long prev_end = 0;
+    for (int kq = 0; kq < 5; ++kq) {
+      long long lo = -1, hi = 0; double ph[5] = {0, 0, 0, 0, 0}; int cnt = 0;
+      for (int g = 0; g < pp.nwg; ++g) {
+        const long long* d = &h[((size_t)kq * pp.nwg + g) * 8];
+        if (d[0] == 0 || d[5] == 0) continue;
+        if (lo < 0 || d[0] < lo) lo = d[0];
+        if (d[5] > hi) hi = d[5];
+        for (int q = 0; q < 5; ++q) ph[q] += (double)(d[q + 1] - d[q]);
+        ++cnt;
+      }
+      if (cnt == 0) continue;
+      std::fprintf(stderr, "[stamps pipe %s] workgroups %d: first entry -> last exit %.2f us (gap to previous kernel's last exit %.2f us); per wave: issue %.2f, loads land %.2f, chain %.2f, epilogue %.2f, stores drain %.2f us\n",
+                   names[kq], cnt, 0.01 * (hi - lo), prev_end ? 0.01 * (lo - prev_end) : 0.0, 0.01 * ph[0] / cnt, 0.01 * ph[1] / cnt, 0.01 * ph[2] / cnt, 0.01 * ph[3] / cnt, 0.01 * ph[4] / cnt);
+      prev_end = hi;
+    }
+  }
+#endif
   HIPCHK(hipMemcpy(out, dw.p, tot * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(basis, dV.p, tot * sizeof(double), hipMemcpyDeviceToHost));
   if (state) HIPCHK(hipMemcpy(state, drs.p, 4 * (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));

@@ -114,6 +114,8 @@ struct ProjArgs {
   double refine_loose;    // >= 1: the one-off acceptance level of an isolated near miss, as a multiple of refine_acc (1 = off)
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
+  const int* pmode;       // per block, may be null: != 0 = the tile-parallel pipeline launched in front (refine_pipe.hpp) has already
+                          // projected this block in this iteration; the workgroup returns at once
 };
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
@@ -266,6 +268,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   static_assert(!PK || (!V_LDS && NT == 1024), "packed variant: V in HBM, 1024 threads");
   static_assert(!PP || (V_LDS && NT == 1024 && (RPW == 5 || RPW == 6 || RPW == 7)), "ping-pong sweeps: V in LDS, 1024 threads");
   extern __shared__ double lds[];
+  if (a.pmode && a.pmode[k] != 0) return;      // (uniform over the workgroup, in front of every barrier)
   const int n = a.cn[k];
   const int np = (n + 1) & ~1;   // Jacobi dimension (even)
   const int npg = (n + 15) & ~15;  // storage / MFMA dimension (multiple of 16; zero rows, identity in V)
