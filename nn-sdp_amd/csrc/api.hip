@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <future>
 #include <memory>
@@ -226,6 +227,13 @@ __global__ void k_big_rescale(long long n2, const double* __restrict__ w, double
   if (i < n2 && kap != 1.0) { double wv = w[i]; nu[i] = wv + kap * (nu[i] - wv); }
 }
 
+// the library eigensolver's convergence report, made sticky: a failure of ANY call since the solver was created stays visible
+// (big_info[slot] itself is overwritten by the next call of that slot)
+__global__ void k_sticky_info(const rocblas_int* __restrict__ info, int* __restrict__ flag) { if (*info != 0) *flag = 1; }
+// acc[7] (the control block's flag word: time limit of any rank in its low part) += 1024 when the sticky failure flag is set, so that
+// the flag travels through the check iteration's all-reduce and every rank takes the NUMERICAL_ERROR exit together
+__global__ void k_fold_flag(const int* __restrict__ flag, double* __restrict__ acc7) { if (*flag != 0) *acc7 += 1024.0; }
+
 // w_k = proj_PSD(sym(nu_k)) for one block of any size through rocSOLVER dsyevd + rocBLAS dgemm, all on the handle's stream
 static void project_big_block(rocblas_handle h, hipStream_t st, int n, const double* nuk, double* wk, double* A, double* T, double* Dv,
                               double* Ev, rocblas_int* info, double* eig_out = nullptr) {
@@ -307,6 +315,8 @@ struct nnsdp_solver {
   DBuf<long long> d_coff_s;
   DBuf<double> big_A, big_T, big_D, big_E;
   DBuf<rocblas_int> big_info;
+  DBuf<int> big_flag;                   // sticky: some library eigensolve of this process reported info != 0 (k_sticky_info)
+  int big_flag_host = 0;
   bool v_lds = true;
   int proj_alg = 0;
   size_t lds_bytes = 0;
@@ -339,8 +349,11 @@ struct nnsdp_solver {
   int graph_iters = 0;
   bool graph_pipe = false;              // the captured iterations contain the tile-parallel pipeline
   // tile-parallel form of the refinement stage (refine_pipe.hpp): five short launches over the whole chip in front of the one-CU kernel.
-  // pipe_mode 0: never, 1 (default): switched on / off at check iterations from the share of block visits the stage carries (the first
-  // ~2 000 iterations of a solve run the exact sweeps: the pipeline's launches would be pure overhead there), 2: always (diagnostic)
+  // pipe_mode 0: never; 1 (default): for launches whose largest block is above 96 (the packed variant's range: 0.30 ms -> 71 us per
+  // launch of 106 + 4 x 151; at blocks up to 96 the five launches - ~1.7 us between two of them, 6-10 us each whatever the block
+  // count, bound by the CU's vector-memory issue rate - only tie with the one-CU stage's 56 us), switched on / off
+  // at check iterations from the share of block visits the stage carries (the first ~2 000 iterations of a solve run the exact sweeps:
+  // the pipeline's launches would be pure overhead there); 2: as 1 for every block size (diagnostic); 3: always on (diagnostic)
   nnsdp::RefinePipe pipe;
   int pipe_mode = 1;
   bool pipe_on = false;
@@ -449,6 +462,7 @@ struct nnsdp_solver {
       build_compact_lists(0, ncl);
       big_A.alloc((size_t)nmax * nmax); big_T.alloc((size_t)nmax * nmax); big_D.alloc(nmax); big_E.alloc(nmax);
       big_info.alloc(big_idx.size()); big_info.zero();
+      big_flag.alloc(1); big_flag.zero();
     }
     const int nsm = std::max(nmax_small, 1);
     if (const char* e = std::getenv("NNSDP_REFINE")) opt.proj_refine = std::atoi(e);                   // (diagnostic override, read before the variant is chosen)
@@ -749,7 +763,19 @@ struct nnsdp_solver {
     if (comm && !(std::getenv("NNSDP_NO_RCCL_GRAPH") && std::atoi(std::getenv("NNSDP_NO_RCCL_GRAPH")) != 0)) {
       hipGraph_t pg = nullptr;
       hipGraphExec_t pe = nullptr;
+      // (the probe itself contains a collective: a rank whose capture does not even begin must not leave its peers alone in it -
+      // the 'capture began' bit is agreed on eagerly first, and the capture is ended again without the call where any rank failed)
       bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      {
+        hipGraph_t g0 = nullptr;
+        if (ok) ok = hipStreamEndCapture(st, &g0) == hipSuccess;
+        if (g0) (void)hipGraphDestroy(g0);
+        std::vector<double> cb(1, ok ? 0.0 : 1.0);
+        allreduce_host(cb);
+        ok = cb[0] == 0.0 && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        // (a failure of THIS second begin after the first one succeeded on every rank is not expected; it would leave the peers in
+        // the captured call below, which records a node and returns - nothing blocks inside a capture)
+      }
       if (ok) {
         Rccl& R = Rccl::get();
         const int rc = R.AllReduce(hsum.p, hsum.p, (size_t)S.NE, Rccl::kFloat64, Rccl::kSum, comm, st);
@@ -757,6 +783,12 @@ struct nnsdp_solver {
         ok = rc == 0 && ec == hipSuccess && pg != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&pe, pg, nullptr, nullptr, 0) == hipSuccess;
+      {
+        // the replay EXECUTES the collective: only when every rank holds an instantiated graph
+        std::vector<double> cb(1, ok ? 0.0 : 1.0);
+        allreduce_host(cb);
+        ok = cb[0] == 0.0;
+      }
       if (ok) ok = hipGraphLaunch(pe, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
       if (pe) (void)hipGraphExecDestroy(pe);
       if (pg) (void)hipGraphDestroy(pg);
@@ -807,8 +839,9 @@ struct nnsdp_solver {
     if (big_idx.empty()) lst.assign(cn.begin() + k0, cn.begin() + k1);
     else for (int k : proj_small) lst.push_back(cn[k]);
     if (lst.empty()) return;
+    if (pipe_mode == 1 && *std::max_element(lst.begin(), lst.end()) <= 96) return;
     HIPCHK(pipe.build(lst.data(), (int)lst.size(), nmat));
-    pipe_on = pipe.ready && pipe_mode == 2;
+    pipe_on = pipe.ready && pipe_mode == 3;
   }
   void enqueue_proj(bool warm) {
     ProjArgs a{};
@@ -845,6 +878,7 @@ struct nnsdp_solver {
       double* nuk = nu.p + S.ng + coff[k];
       double* wk = w.p + S.ng + coff[k];
       project_big_block(roc->h, strm, n, nuk, wk, big_A.p, big_T.p, big_D.p, big_E.p, big_info.p + big_slot(k));
+      hipLaunchKernelGGL(k_sticky_info, dim3(1), dim3(1), 0, strm, big_info.p + big_slot(k), big_flag.p);
       hipLaunchKernelGGL(k_big_rescale, dim3(cdiv((long long)n * n, 256)), dim3(256), 0, strm, (long long)n * n, wk, nuk, d_kappa());
     }
     if (strm != st) RBCHK(rocblas_set_stream(roc->h, st));
@@ -905,6 +939,7 @@ struct nnsdp_solver {
       const double tflag = (opt.max_time > 0 && loop_t0 > 0 && now_s() - loop_t0 > opt.max_time) ? 1.0 : 0.0;
       tflag_host = tflag;
       HIPCHK(hipMemcpyAsync(acc.p + 7, &tflag_host, sizeof(double), hipMemcpyHostToDevice, st));
+      if (!big_idx.empty()) hipLaunchKernelGGL(k_fold_flag, dim3(1), dim3(1), 0, st, big_flag.p, acc.p + 7);      // (only block owners run dsyevd)
       allreduce(acc.p, 8 + (size_t)ng);
       HIPCHK(hipMemcpyAsync(nu.p, acc.p + 8, (size_t)ng * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
@@ -976,13 +1011,18 @@ struct nnsdp_solver {
     enqueue_iteration(true, next_is_warm());
     ++iters_done;
     HIPCHK(hipMemcpyAsync(acc_host, acc.p, sizeof(acc_host), hipMemcpyDeviceToHost, st));
-    if (pipe.ready && pipe_mode == 1) HIPCHK(hipMemcpyAsync(stats_host, d_stats.p, sizeof(stats_host), hipMemcpyDeviceToHost, st));
+    if (pipe.ready && pipe_mode != 3) HIPCHK(hipMemcpyAsync(stats_host, d_stats.p, sizeof(stats_host), hipMemcpyDeviceToHost, st));
   }
   void check_finish() {
     HIPCHK(hipStreamSynchronize(st));
-    if (!big_idx.empty())     // rocSOLVER's convergence report of the library eigensolves since the last check
-      for (rocblas_int v : big_info.download()) big_fail = big_fail || v != 0;
-    if (pipe.ready && pipe_mode == 1) {
+    // rocSOLVER's convergence report of the library eigensolves, sticky since the solver was created.  Clique-sharded: only a block's
+    // owner runs dsyevd, so the flag rides in the all-reduced control block (acc[7] >= 1024) and all ranks leave the loop together;
+    // a rank-local exit would strand the others in the next iteration's all-reduce.
+    if (!big_idx.empty()) {
+      if (sharded) big_fail = big_fail || acc_host[7] >= 1024.0;
+      else big_fail = big_fail || big_flag.download()[0] != 0;
+    }
+    if (pipe.ready && pipe_mode != 3) {
       // the pipeline pays once the stage carries the block visits (late phase); while the sweeps run it is five empty launches per
       // iteration.  Decided from the counters of the window since the last check (deterministic: no timing enters), with hysteresis.
       const long long carried = (long long)stats_host[4] + stats_host[5] + stats_host[8];
@@ -1093,7 +1133,7 @@ struct nnsdp_solver {
       if (flag[1] != 0.0) throw HipError(lead() ? err : std::string("rank 0 failed while polishing the certificate"));
       if (flag[0] != 0.0) return NNSDP_STATUS_OPTIMAL;
     }
-    if (!advance_only && opt.max_time > 0 && (sharded ? acc_host[7] > 0.0 : now_s() - t0 > opt.max_time)) return NNSDP_STATUS_TIME_LIMIT;
+    if (!advance_only && opt.max_time > 0 && (sharded ? std::fmod(acc_host[7], 1024.0) > 0.0 : now_s() - t0 > opt.max_time)) return NNSDP_STATUS_TIME_LIMIT;
     // stall detector (MOSEK's SLOW_PROGRESS analogue): no 10 % improvement of the larger residual in 50 000 iterations
     {
       double worst = std::max(last_pres, last_dres);
@@ -1332,14 +1372,27 @@ struct nnsdp_solver {
   }
 
   void finish(nnsdp_result* r, int status) {
-    // final Z and certificate in the reference's coordinates
-    if (!full) {
-      if (full_fut.valid()) { full = full_fut.get(); full->upload(); }
-      else {
-        full.reset(new FullOperator());
-        nnsdp_problem pp = problem_view();
-        full->build(&pp);
+    // final Z and certificate in the reference's coordinates.  Clique-sharded: this preparation is rank-local and can fail on ANY
+    // rank (host allocation in the builder thread, upload), and the certificate below is a collective - so the outcome of the
+    // preparation travels first, and every rank throws together instead of one leaving the others inside the all-reduce
+    {
+      std::vector<double> pflag(1, 0.0);
+      std::string perr;
+      try {
+        if (!full) {
+          if (full_fut.valid()) { full = full_fut.get(); full->upload(); }
+          else {
+            full.reset(new FullOperator());
+            nnsdp_problem pp = problem_view();
+            full->build(&pp);
+          }
+        }
+      } catch (const std::exception& e) {
+        if (!sharded) throw;
+        perr = e.what(); pflag[0] = 1.0;
       }
+      allreduce_host(pflag);
+      if (pflag[0] != 0.0) throw HipError(!perr.empty() ? perr : std::string("another rank failed while preparing the certificate's operator"));
     }
     std::vector<double> gam(P.ng, 0.0);
     DBuf<double> Zd;
@@ -2114,24 +2167,33 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   if (kernel_ms) *kernel_ms = ms;
 #ifdef NNSDP_STAMPS
   if (use_pipe && pp.ready) {
-    // (diagnostic build) wall-clock stamps (100 MHz) of the stamping wave of every workgroup: spans and phase averages per kernel
+    // (diagnostic build) wall-clock stamps (100 MHz) of thread 0 of every workgroup: spans and phase averages per kernel
     std::vector<long long> h = ddbg.download();
     const char* names[5] = {"T", "B", "X", "V", "W"};
     long long prev_end = 0;
     for (int kq = 0; kq < 5; ++kq) {
-      long long lo = -1, hi = 0; double ph[5] = {0, 0, 0, 0, 0}; int cnt = 0;
+      long long lo = -1, hi = 0; double ph[4] = {0, 0, 0, 0}; int cnt = 0;
       for (int g = 0; g < pp.nwg; ++g) {
         const long long* d = &h[((size_t)kq * pp.nwg + g) * 8];
-        if (d[0] == 0 || d[5] == 0) continue;
+        if (d[0] == 0 || d[4] == 0 || d[3] == 0) continue;
         if (lo < 0 || d[0] < lo) lo = d[0];
-        if (d[5] > hi) hi = d[5];
-        for (int q = 0; q < 5; ++q) ph[q] += (double)(d[q + 1] - d[q]);
+        if (d[4] > hi) hi = d[4];
+        for (int q = 0; q < 4; ++q) ph[q] += (double)(d[q + 1] - d[q]);
         ++cnt;
       }
       if (cnt == 0) continue;
-      std::fprintf(stderr, "[stamps pipe %s] workgroups %d: first entry -> last exit %.2f us (gap to previous kernel's last exit %.2f us); per wave: issue %.2f, loads land %.2f, chain %.2f, epilogue %.2f, stores drain %.2f us\n",
-                   names[kq], cnt, 0.01 * (hi - lo), prev_end ? 0.01 * (lo - prev_end) : 0.0, 0.01 * ph[0] / cnt, 0.01 * ph[1] / cnt, 0.01 * ph[2] / cnt, 0.01 * ph[3] / cnt, 0.01 * ph[4] / cnt);
+      std::fprintf(stderr, "[stamps pipe %s] workgroups %d: first entry -> last exit %.2f us (gap to previous kernel's last exit %.2f us); thread 0: strips staged %.2f, barrier %.2f, chain %.2f, epilogue %.2f us\n",
+                   names[kq], cnt, 0.01 * (hi - lo), prev_end ? 0.01 * (lo - prev_end) : 0.0, 0.01 * ph[0] / cnt, 0.01 * ph[1] / cnt, 0.01 * ph[2] / cnt, 0.01 * ph[3] / cnt);
       prev_end = hi;
+      if (kq == 3) {
+        double f[3] = {0, 0, 0}; int c2 = 0;
+        for (int g = 0; g < pp.nwg; ++g) {
+          const long long* d = &h[((size_t)kq * pp.nwg + g) * 8];
+          if (d[0] == 0 || d[5] == 0 || d[6] == 0 || d[7] == 0) continue;
+          f[0] += (double)(d[5] - d[0]); f[1] += (double)(d[6] - d[5]); f[2] += (double)(d[7] - d[6]); ++c2;
+        }
+        if (c2) std::fprintf(stderr, "[stamps pipe V, inside 'strips staged'] block size known (scalar loads) %.2f, all vector loads issued +%.2f, landed +%.2f us\n", 0.01 * f[0] / c2, 0.01 * f[1] / c2, 0.01 * f[2] / c2);
+      }
     }
   }
 #endif

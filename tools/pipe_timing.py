@@ -1,5 +1,5 @@
 """(diagnostic) iterations/s late in a solve with and without the tile-parallel refinement pipeline: advance a handle deep into the
-solve, then time graph-replayed iterations.  NNSDP_PIPE=0/1/2 selects the mode (read at solver creation).
+solve, then time graph-replayed iterations.  NNSDP_PIPE=0/1/2/3 selects the mode (0 never, 1 default, 2 auto for every size, 3 always) (read at solver creation).
 usage: [NNSDP_PIPE=..] python tools/pipe_timing.py [workload=W40-D20] [mode=single] [advance=8000] [timed=4000]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
