@@ -151,7 +151,7 @@ def test_gram_product_is_skipped_three_visits_in_four_and_the_defect_estimate_ho
     assert credits[1] == [2, 2, 2] and credits[2] == [1, 1, 1] and credits[3] == [0, 0, 0] and credits[4] == [3, 3, 3]
 
 
-@pytest.mark.parametrize("n", [57, 85, 151])
+@pytest.mark.parametrize("n", [57, 85, 101, 128, 151])
 def test_one_unresolvable_pair_across_zero_is_rotated_exactly(n, monkeypatch):
     """the late-solve rejection: ONE pair of eigenvalues on either side of zero whose coupling is far above their gap (first order cannot
     resolve it, and it counts whichever side the projection is rebuilt from).  The stage rotates that pair exactly and takes its step;
@@ -181,7 +181,7 @@ def test_one_unresolvable_pair_across_zero_is_rotated_exactly(n, monkeypatch):
     assert np.linalg.norm(W0[0] - Wx) <= tol * np.linalg.norm(A1)
 
 
-@pytest.mark.parametrize("n", [129, 151, 160])
+@pytest.mark.parametrize("n", [97, 101, 103, 128, 129, 151, 160])      # (97 .. 128: the variant a solver's warm iterations take with the stage on)
 @pytest.mark.parametrize("eta", [1e-4, 1e-6])
 def test_packed_variant_takes_the_refinement_step(n, eta):
     """blocks 129 .. 160 (the reference's 151-wide cliques of width-50 networks): the stage in its packed form - antisymmetric K in the
@@ -206,7 +206,7 @@ def test_packed_variant_persistent_basis_and_fall_back():
     """the packed stage over 20 consecutive small moves with its state carried (Gram product on one visit in four), then a large move
     that must go on to the sweeps, then a basis with a defect that the Gram visit has to remove (Newton-Schulz pass + congruence again)"""
     rng = np.random.default_rng(5)
-    ns = [151, 106, 160]
+    ns = [151, 106, 160, 101, 128]
     mats, bases = [], []
     for n in ns:
         spec = np.concatenate([np.linspace(0.05, 2.0, n - n // 3), -np.linspace(0.05, 1.0, n // 3)])
@@ -252,3 +252,105 @@ def test_solver_with_and_without_refinement_agree():
     assert off.summary["refine_blocks"] == [0, 0, 0, 0, 0]
     assert rb[1] > 0 and sum(rb) > 0
     print("refinement block visits [converged, one step, sweeps, skipped, checked step]:", rb, "iters", on.summary["iters"], off.summary["iters"])
+
+
+# ---- the tile-parallel pipeline (csrc/refine_pipe.hpp): refine = 4 of the warm entry puts its five launches in front of the kernel ----
+
+@pytest.mark.parametrize("n", [41, 57, 68, 85, 96, 97, 101, 103, 121, 128, 129, 151, 160])
+@pytest.mark.parametrize("neg_share", [1 / 3, 0.7])
+def test_pipeline_one_step_meets_its_tolerance(n, neg_share):
+    """the same step as the kernel's stage, spread over the chip: a slowly moving matrix takes it and the projection is within the level
+    it promises of LAPACK's, rebuilt from the positive side (few positive eigenvalues... or many: the negative side, W = sym(nu) - sum),
+    the result exactly symmetric, the basis orthogonal to second order; several blocks of mixed sizes in one launch"""
+    rng = np.random.default_rng(n)
+    m = max(1, int(n * neg_share))
+    spec = np.concatenate([np.linspace(0.2, 2.0, n - m), -np.linspace(0.1, 1.5, m)])
+    eta, tol = 1e-6, 3e-7
+    base = [_sym(rng, n, spec), _sym(rng, max(n - 13, 17), np.linspace(-1.0, 1.3, max(n - 13, 17))), _sym(rng, n, spec[::-1].copy())]
+    mats = [_perturb(rng, A, eta) for A, _ in base]
+    W, V, oc, _ = na.project_psd_warm(mats, [Q for _, Q in base], tol, refine=4)
+    assert oc == [0, 3, 0, 0, 0], oc
+    for A, Wk, Vk in zip(mats, W, V):
+        assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * tol * np.linalg.norm(A)
+        assert np.abs(Wk - Wk.T).max() == 0.0
+        assert np.linalg.norm(Vk.T @ Vk - np.eye(len(A))) <= 1e-3
+    # the one-CU stage on the same input takes the same decision and lands on the same projection
+    W1, V1, oc1, _ = na.project_psd_warm(mats, [Q for _, Q in base], tol, refine=1)
+    if n > 40:
+        assert oc1 == oc
+    for Wa, Wb, A in zip(W, W1, mats):
+        assert np.linalg.norm(Wa - Wb) <= 30 * tol * np.linalg.norm(A)
+
+
+@pytest.mark.parametrize("n", [68, 85, 101, 151])
+def test_pipeline_converged_blocks_and_fall_back(n):
+    """a block that arrives converged is rebuilt from its basis as it is (no step); a block that moved too far is left to the kernel
+    launched behind the pipeline (its sweeps: exact); both in one launch"""
+    rng = np.random.default_rng(100 + n)
+    spec = np.concatenate([np.linspace(0.2, 2.0, n - n // 3), -np.linspace(0.1, 1.5, n // 3)])
+    A0, Q0 = _sym(rng, n, spec)
+    A1, Q1 = _sym(rng, n, spec)
+    far = _perturb(rng, A1, 3e-2)
+    tol = 1e-7
+    W, V, oc, _ = na.project_psd_warm([A0, far], [Q0, Q1], tol, refine=4)
+    assert oc[0] == 1 and oc[2] == 1, oc
+    assert np.linalg.norm(W[0] - oadmm.project_psd(A0)) <= tol * np.linalg.norm(A0)
+    assert np.linalg.norm(W[1] - oadmm.project_psd(far)) <= tol * np.linalg.norm(far)
+    assert np.linalg.norm(V[1].T @ V[1] - np.eye(n)) <= 1e-9
+
+
+def test_pipeline_persistent_basis_over_many_steps():
+    """40 consecutive small moves through the pipeline with the state carried, each from the basis the previous call returned: the Gram
+    product on one visit in four, the defect estimate above the measured defect, every projection inside the promised level"""
+    rng = np.random.default_rng(31)
+    ns = [57, 85, 106, 151]
+    mats, bases = [], []
+    for n in ns:
+        spec = np.concatenate([np.linspace(0.05, 2.0, n - n // 3), -np.linspace(0.05, 1.0, n // 3)])
+        A, Q = _sym(rng, n, spec)
+        mats.append(A)
+        bases.append(Q)
+    eta, tol = 3e-5, 1e-5
+    state = np.zeros(4 * len(ns), dtype=np.int32)
+    steps, credits = 0, []
+    for it in range(40):
+        mats = [_perturb(rng, A, eta) for A in mats]
+        W, bases, oc, _ = na.project_psd_warm(mats, bases, tol, refine=4, state=state)
+        steps += oc[1]
+        words = state.reshape(-1, 4)
+        credits.append([(int(w) >> 24) & 15 for w in words[:, 0]])
+        est = words[:, 2:4].copy().view(np.float64).ravel()
+        for k, (A, Wk, Vk) in enumerate(zip(mats, W, bases)):
+            assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * tol * np.linalg.norm(A), (it, k)
+            assert np.linalg.norm(Vk.T @ Vk - np.eye(len(A))) <= max(est[k], 1e-13) * 1.01 + 1e-13
+    assert steps >= 150
+    assert credits[0] == [3] * 4 and credits[1] == [2] * 4 and credits[3] == [0] * 4 and credits[4] == [3] * 4
+
+
+@pytest.mark.parametrize("pipe", ["3", "1"])
+def test_solver_with_the_pipeline_agrees(pipe, monkeypatch):
+    """whole solves with the pipeline (NNSDP_PIPE = 3: always on, blocks up to 85; 1: the default rule on a width-50 network in the Path
+    decomposition, blocks of 101) and without it: same optimum, comparable iteration counts, the stage carries the block visits"""
+    if pipe == "3":
+        q = helpers.product_query(helpers.load_problem("W40-D20", 0))
+        opts = dict(max_iters=60000, eps_rel=1e-6, decomp_mode=na.DoubleDecomp())
+    else:
+        from nnsdp_amd import frontend as F
+        from oracle import nnet_io
+        onet = nnet_io.random_net([5] + [50] * 6 + [5], seed=1)
+        net = na.FeedFwdNet(xdims=onet.xdims, Ms=onet.Ms)
+        lo, hi = np.full(5, 0.25), np.full(5, 0.35)
+        xi, acx = F.intervalsWorstCase(lo, hi, net)
+        nrm = np.zeros(5); nrm[0] = 1.0
+        q = na.ReachQuery(ffnet=net, qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_reach=na.QcReachHplane(normal=nrm), qc_activs=F.makeQcActivsIntvs(net, xi, acx, 0))
+        opts = dict(max_iters=60000, eps_rel=1e-5, decomp_mode=na.PathDecomp())
+    monkeypatch.setenv("NNSDP_PIPE", "0")
+    off = na.runQuery(q, na.AdmmSdpOptions(**opts))
+    monkeypatch.setenv("NNSDP_PIPE", pipe)
+    on = na.runQuery(q, na.AdmmSdpOptions(**opts))
+    assert on.termination_status == off.termination_status == "OPTIMAL"
+    assert abs(on.summary["objective_admm"] - off.summary["objective_admm"]) <= 2e-5 * abs(off.summary["objective_admm"])
+    assert abs(on.objective_value - off.objective_value) <= 1e-5 * abs(off.objective_value)
+    assert abs(on.summary["iters"] - off.summary["iters"]) <= 0.25 * off.summary["iters"]
+    assert on.summary["lambda_max"] <= 1e-7
+    print("solve seconds with / without the pipeline:", on.solve_time, off.solve_time, "block visits", on.summary["refine_blocks"])
