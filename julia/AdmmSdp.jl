@@ -11,6 +11,7 @@ const LIBNNSDP = get(ENV, "NNSDP_LIB", "libnnsdp_hip.so")
 
 # extension: cliques {x_k, x_{k+1}, affine index}; exact whenever the output QC has no x_1 -- x_K coupling (S12 = 0)
 struct PathDecomp <: DecompMode end
+struct AutoDecomp <: DecompMode end      # PathDecomp when the query allows it, DoubleDecomp otherwise (nnsdp.h: NNSDP_DECOMP_AUTO)
 
 @with_kw struct AdmmSdpOptions <: QueryOptions
   decomp_mode::DecompMode = SingleDecomp()   # SingleDecomp / DoubleDecomp / DoubleRelaxDecomp (chordal_sdp.jl:4-8) / PathDecomp
@@ -82,7 +83,7 @@ function runQuery(query::Query, opts::AdmmSdpOptions)
   gin = zeros(query.qc_input.vardim); gout = zeros(1); gac1 = zeros(qb.vardim); gac2 = zeros(qs.vardim)
   Z = zeros(Zdim, Zdim)
   # DoubleRelaxDecomp is treated exactly like DoubleDecomp by the reference (chordal_sdp.jl:25)
-  mode = opts.dense ? Int32(0) : opts.decomp_mode isa SingleDecomp ? Int32(1) : opts.decomp_mode isa PathDecomp ? Int32(3) : Int32(2)
+  mode = opts.dense ? Int32(0) : opts.decomp_mode isa SingleDecomp ? Int32(1) : opts.decomp_mode isa PathDecomp ? Int32(3) : opts.decomp_mode isa AutoDecomp ? Int32(4) : Int32(2)
   # obj_func (Methods.jl:41) is affine in γout[1] at every call site (x -> x[1], NnSdp.jl:46,66,87); any increasing affine
   # a*ρ + b has the same minimiser, so it is evaluated on the solution instead of being handed to the solver
   if query isa ReachQuery

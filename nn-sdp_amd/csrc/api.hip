@@ -404,7 +404,7 @@ struct nnsdp_solver {
     if (!(opt.alpha > 0.0 && opt.alpha < 2.0)) throw std::invalid_argument("alpha must be in (0,2)");
     if (!(opt.sigma > 0.0)) throw std::invalid_argument("sigma must be > 0");
     if (opt.check_every <= 0) opt.check_every = 50;
-    if (opt.decomp_mode < NNSDP_DECOMP_DENSE || opt.decomp_mode > NNSDP_DECOMP_PATH)
+    if (opt.decomp_mode < NNSDP_DECOMP_DENSE || opt.decomp_mode > NNSDP_DECOMP_AUTO)
       throw std::invalid_argument("unrecognized decomp_mode");
     const bool tm = std::getenv("NNSDP_SETUP_TIMING") != nullptr;     // diagnostic: where the set-up time goes (stderr)
     double tl = now_s();
@@ -420,15 +420,26 @@ struct nnsdp_solver {
     HIPCHK(hipStreamCreate(&st));
     if (!(opt.interval_guard >= 0.0 && opt.interval_guard < 0.1)) throw std::invalid_argument("interval_guard must be in [0, 0.1)");
     C = make_congruence(P, opt.normalize != 0, opt.interval_guard);
+    // NNSDP_DECOMP_AUTO: the finest exact decomposition the query allows - the path cliques {x_k, x_k+1, affine} when the output QC
+    // does not couple x_1 with x_K (every reach query, hyperplane safety sets: the generator table then fits their pattern, which
+    // is what the builder checks), DoubleDecomp otherwise.  On the ACAS-shaped width-50 query the reference's Single cliques
+    // (106 + 4 x 151) take 13-17 s, the path cliques (6 x 101) 3.6 s.
+    const bool auto_mode = opt.decomp_mode == NNSDP_DECOMP_AUTO;
+    if (auto_mode) opt.decomp_mode = NNSDP_DECOMP_PATH;
     std::vector<std::vector<int>> cl = reduced_cliques(P, C, opt.decomp_mode);
     Pattern pt = build_pattern(C.nred, cl);
     Operator op;
     try {
       op = OperatorBuilder(P, C, pt).build();
     } catch (const std::runtime_error& e) {
-      if (opt.decomp_mode == NNSDP_DECOMP_PATH)
+      if (auto_mode) {
+        opt.decomp_mode = NNSDP_DECOMP_DOUBLE;
+        cl = reduced_cliques(P, C, opt.decomp_mode);
+        pt = build_pattern(C.nred, cl);
+        op = OperatorBuilder(P, C, pt).build();
+      } else if (opt.decomp_mode == NNSDP_DECOMP_PATH)
         throw std::invalid_argument(std::string("PATH decomposition needs an output QC without x_1 -- x_K coupling (S12 = 0): ") + e.what());
-      throw;
+      else throw;
     }
     {
       std::vector<int> layers = P.generator_layers();
@@ -1513,6 +1524,9 @@ struct nnsdp_batch {
       if (sv[i]->sharded) throw std::invalid_argument("clique-sharded solvers cannot be batched");
       if (sv[i]->opt.device != sv[0]->opt.device) throw std::invalid_argument("batched solvers must live on one device");
       if (sv[i]->opt.check_every != sv[0]->opt.check_every) throw std::invalid_argument("batched solvers must share check_every");
+      // (one kernel variant per batched launch, chosen from proj_refine: members that disagree would silently lose - or get - the
+      // refinement stage, and the variant would change whenever the first member finishes)
+      if ((sv[i]->opt.proj_refine != 0) != (sv[0]->opt.proj_refine != 0)) throw std::invalid_argument("batched solvers must share proj_refine (on / off)");
       for (int j = 0; j < i; ++j) if (sv[j] == sv[i]) throw std::invalid_argument("a solver appears twice in the batch");
       all.push_back(sv[i]);
     }
@@ -2259,11 +2273,20 @@ int nnsdp_shard_plan(const nnsdp_problem* p, const nnsdp_options* o, int32_t nra
   API_BEGIN
   if (!p || !o || !n_blocks) throw std::invalid_argument("null argument");
   if (nranks < 1) throw std::invalid_argument("nranks must be >= 1");
-  if (o->decomp_mode < NNSDP_DECOMP_DENSE || o->decomp_mode > NNSDP_DECOMP_PATH) throw std::invalid_argument("unrecognized decomp_mode");
+  if (o->decomp_mode < NNSDP_DECOMP_DENSE || o->decomp_mode > NNSDP_DECOMP_AUTO) throw std::invalid_argument("unrecognized decomp_mode");
   ProblemCopy P;
   P.load(p);
   Congruence C = make_congruence(P, o->normalize != 0, o->interval_guard);
-  auto cl = reduced_cliques(P, C, o->decomp_mode);
+  int mode = o->decomp_mode;
+  if (mode == NNSDP_DECOMP_AUTO) {      // (the solver's own rule: the path cliques when the generator table fits their pattern)
+    mode = NNSDP_DECOMP_PATH;
+    try {
+      auto clp = reduced_cliques(P, C, mode);
+      Pattern ptp = build_pattern(C.nred, clp);
+      (void)OperatorBuilder(P, C, ptp).build();
+    } catch (const std::runtime_error&) { mode = NNSDP_DECOMP_DOUBLE; }
+  }
+  auto cl = reduced_cliques(P, C, mode);
   *n_blocks = (int32_t)cl.size();
   if (block_n || start) {
     std::vector<int> cn(cl.size());

@@ -3,7 +3,7 @@ reference's Methods/Qc API over the C ABI in include/nnsdp.h)."""
 from .methods import (  # noqa: F401
     FeedFwdNet, QcInputBox, QcSafety, QcReachHplane, QcReachCircle, QcReachEllipsoid,
     QcActivBounded, QcActivSector, SafetyQuery, ReachQuery, AdmmSdpOptions, QuerySolution,
-    SingleDecomp, DoubleDecomp, DoubleRelaxDecomp, PathDecomp, DenseCone, Solver, SolverBatch,
+    SingleDecomp, DoubleDecomp, DoubleRelaxDecomp, PathDecomp, AutoDecomp, DenseCone, Solver, SolverBatch,
     runQuery, runQueries, solveQuery, makeZ, adjoint, makeCliques, project_psd_batched, project_psd_warm, comm_unique_id, shardPlan,
 )
 from .frontend import (  # noqa: F401

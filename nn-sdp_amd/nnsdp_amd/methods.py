@@ -61,6 +61,13 @@ class PathDecomp:
     code = 3
 
 
+class AutoDecomp:
+    """extension: PathDecomp when the query allows it (no x_1 -- x_K coupling in the output QC: every reach query, hyperplane safety
+    sets), DoubleDecomp otherwise.  The default stays the reference's own (`decomp_mode::DecompMode = SingleDecomp()`,
+    src/Methods/chordal_sdp.jl:13)."""
+    code = 4
+
+
 DoubleRelaxDecomp = DoubleDecomp   # the reference treats the two identically (src/Methods/chordal_sdp.jl:8,25)
 
 

@@ -63,6 +63,14 @@ def main():
                        pres=float(sol.summary["pres"]), dres=float(sol.summary["dres"]), lambda_max=float(sol.summary["lambda_max"]),
                        gamma=np.concatenate([sol.values[k] for k in ("γin", "γout", "γac1", "γac2")]).tolist())
     s.close()
+    # (d) the DEFAULT configuration (refinement stage on) at the level of the replicated state: 300 plain iterations + one check
+    # iteration; the multiplier block is replicated, so after the check iteration's resynchronisation it is rank 0's bit for bit
+    s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()))
+    s.set_comm_callback(world, rank, allreduce)
+    s.iterate(300)
+    res["refine_after_300"] = list(s.residuals())
+    res["refine_mult301_digest"] = hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest()
+    s.close()
     bn, st = na.shardPlan(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp()), world)
     res["blocks_owned"] = [int(st[rank]), int(st[rank + 1])]
     dist.barrier()

@@ -419,6 +419,14 @@ def test_acas_shaped_safety_query_tracks_oracle():
     with pytest.raises(na._lib.NnsdpError) as ei2:
         na.runQuery(acas2, na.AdmmSdpOptions(max_iters=10, decomp_mode=na.PathDecomp()))
     assert "S12" in str(ei2.value)
+    # AutoDecomp (nnsdp.h: NNSDP_DECOMP_AUTO) takes the path cliques where the query allows them and the Double ones where not
+    sa = na.runQuery(acas, na.AdmmSdpOptions(max_iters=60, decomp_mode=na.AutoDecomp()))
+    assert (sa.summary["n_cliques"], sa.summary["max_clique"]) == (sp.summary["n_cliques"], sp.summary["max_clique"])
+    assert sa.objective_value == sp.objective_value
+    sd2 = na.runQuery(acas2, na.AdmmSdpOptions(max_iters=60, decomp_mode=na.DoubleDecomp()))
+    sa2 = na.runQuery(acas2, na.AdmmSdpOptions(max_iters=60, decomp_mode=na.AutoDecomp()))
+    assert (sa2.summary["n_cliques"], sa2.summary["max_clique"]) == (sd2.summary["n_cliques"], sd2.summary["max_clique"])
+    assert sa2.objective_value == sd2.objective_value
     iters = 400
     s = na.runQuery(q, na.AdmmSdpOptions(max_iters=iters, proj_tol=1e-12, polish=False))
     r = oadmm.admm_solve(oop.build_operator(qo, "single", normalize=True), oadmm.AdmmOptions(max_iters=iters))
@@ -516,7 +524,10 @@ def test_clique_sharded_mode_single_rank_rccl():
     # the sharded iteration replays a hipGraph with the ncclAllReduce inside it when this ROCm's RCCL can be captured (probed at set_comm)
     print("RCCL all-reduce capturable into a hipGraph:", bool(graphs[1]), "- graph launches in 250 iterations:", int(graphs[0]))
     assert (graphs[0] > 0) == bool(graphs[1])
-    import time
+    import json, time
+    os.makedirs(os.path.join(helpers.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(helpers.ROOT, "gpurun_out", "rccl_one_rank_graph.json"), "w") as fh:      # (a silently eager fall-back shows here)
+        json.dump({"rccl_allreduce_capturable": bool(graphs[1]), "graph_launches_in_250_iterations": int(graphs[0])}, fh)
     for capture in ("1", "0"):       # control-flow cost of the sharded iteration on one card: eager vs graph replay vs unsharded
         os.environ["NNSDP_NO_RCCL_GRAPH"] = "0" if capture == "1" else "1"
         e = na.Solver(helpers.product_query(helpers.load_problem("W40-D20", 0)), na.AdmmSdpOptions(max_iters=10 ** 8))

@@ -82,8 +82,13 @@ def test_two_rank_sharded_solve_matches_the_serial_solve(name, beta, tmp_path):
     # (c) the certified-gap rule under sharding: one decision (rank 0 polishes, the flag is all-reduced), one certificate
     ca, cb = r0["cert"], r1["cert"]
     assert ca["status"] == cb["status"] == refc.termination_status == "OPTIMAL"
-    assert ca["iters"] == cb["iters"] and ca["iters"] < a["iters"] + 10**9
+    assert ca["iters"] == cb["iters"]
+    assert ca["iters"] <= 2 * refc.summary["iters"] + 500          # (the rule fires at the serial solve's check point or one of the next few)
     assert np.array_equal(np.array(ca["gamma"]), np.array(cb["gamma"]))
     assert max(ca["pres"], ca["dres"]) > 1e-7                       # it was the certified-gap rule that stopped the solve
     assert abs(ca["rho"] - refc.objective_value) <= 1e-3 * abs(refc.objective_value)
     assert ca["lambda_max"] <= 1e-6 and min(ca["gamma"]) >= 0.0
+    # (d) with the refinement stage on (the default): the control numbers and the resynchronised multiplier block are bit-identical
+    # on both ranks (the stage's accept / reject decisions are taken by each block's owner alone; nothing replicated depends on them)
+    assert r0["refine_after_300"] == r1["refine_after_300"]
+    assert r0["refine_mult301_digest"] == r1["refine_mult301_digest"]
