@@ -15,10 +15,12 @@ torch.distributed.run, one rank per GPU.  One JSON line on rank 0.
              synchronises and takes the max over ranks; the data-path collective is the library's own ncclAllReduce.
              If the sharded leg cannot start (RCCL unavailable), `value` falls back to the replica figure and says so.
              See DESIGN.md "Multi-GPU".
-  * roofline: the projection kernel is compute bound (fp64), so `bound` = "mfma" with the fp64
-             vector/matrix peak; achieved = algorithmic flops (10 * sum n_k^3 of the blocks solved)
-             / average kernel duration from HIP events recorded on the solver's stream inside the
-             timed region.  The HBM-side figures the north star asks for are reported as hbm_*.
+  * roofline: the north star scores the eigendecomposition (projection) kernel against HBM bandwidth, so `bound` = "hbm":
+             achieved = algorithmic bytes per launch / average duration of the projection launch(es) from HIP events recorded on
+             the solver's stream inside the timed region.  Algorithmic bytes: SURVEY.md section 8(d)'s 2 x 8 x sum n_k^2 (nu read,
+             w written) PLUS the persistent eigenbasis, read and written once per launch by design (another 2 x 8 x sum n_k^2 -
+             it is the state the refinement stage updates); both figures are in the object.  The fp64 matrix-pipe figure
+             (10 x sum n_k^3 flop against 78.6 TFLOP/s), which is what actually bounds the kernel, rides beside it under "mfma".
   * cpu_baseline: the C++/OpenMP port of the same ADMM iteration (oracle/c, LAPACK dsyevd per clique) timed on the host
              cores for a bounded sample, plus its estimated time to the certificates the GPU solves reached.
 """
@@ -216,7 +218,7 @@ def main():
     # call first, and at least 256 iterations are timed whatever --steps is (a 20-step window used to contain the capture)
     solver.iterate(64)                  # every rank runs these too (sharded mode: collective inside)
     torch.cuda.synchronize()
-    g_steps = max(args.steps, 256)
+    g_steps = max(args.steps, 2048)
     tg0 = time.perf_counter()
     solver.iterate(g_steps)
     torch.cuda.synchronize()
@@ -247,7 +249,7 @@ def main():
         # (tools/collect_profiles.sh), so the figure is read from the committed summary of the SAME workload and build round
         # and labelled as such; absent or for another workload it stays null
         traffic, traffic_source = None, None
-        pmc_file = os.path.join(ROOT, "profiles", f"r03_pmc_counters_{args.workload}.json")
+        pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_counters_{args.workload}.json") for r in range(9, 0, -1)) if os.path.exists(f)), "")
         if args.beta == 0 and os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
@@ -268,6 +270,7 @@ def main():
             flops = float(sum(10 * n ** 3 for n in bn[st[0]:st[1]]))
             byts = float(sum(16 * n ** 2 for n in bn[st[0]:st[1]]))
         ach_tf = flops / eig_avg_s / 1e12
+        byts_basis = 2.0 * byts          # + the persistent eigenbasis: read and written once per launch
         out = {
             "metric": "ADMM iters/sec + wall-clock to eps-cert, bench/rand W=40 D=20",
             "value": (1 if shard or world == 1 else world) * args.steps / dt,
@@ -285,19 +288,26 @@ def main():
                                    + ("" if world == 1 else (f"; ONE SDP, cliques sharded over {world} GPUs, RCCL all-reduce per iteration" if shard
                                                              else f"; {world} independent SDPs, one per GPU")),
                        "parallelism": ("clique-sharded, 1 all-reduce/iteration" if shard else "1 SDP per GPU, cliques batched in one launch")},
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_proj_jacobi (refinement stage + ping-pong sweeps, one launch)", "kernel_avg_us": eig_avg_s * 1e6,
-                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
-                         "hbm_achieved_GBs": byts / eig_avg_s / 1e9, "hbm_frac": byts / eig_avg_s / 1e9 / HBM_PEAK_GBS},
+            "roofline": {"bound": "hbm", "achieved": byts_basis / eig_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": byts_basis / eig_avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "k_proj_jacobi (refinement stage + ping-pong sweeps, one launch per step; with blocks above 96 the five k_pipe_* launches in front of it are inside the same events)",
+                         "kernel_avg_us": eig_avg_s * 1e6,
+                         "algorithmic_bytes_per_launch": byts_basis,
+                         "algorithmic_bytes_note": "2 x 8 x sum n_k^2 (nu read, w written: SURVEY section 8d) + 2 x 8 x sum n_k^2 (persistent eigenbasis read and written)",
+                         "survey_8d_bytes_per_launch": byts, "survey_8d_frac": byts / eig_avg_s / 1e9 / HBM_PEAK_GBS,
+                         "mfma": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
+                                  "algorithmic_flops_per_launch": flops,
+                                  "note": "what bounds the kernel: one SDP's 19 blocks occupy 19 of 256 CUs and live on those CUs' fp64 matrix pipes (DESIGN.md section 4)"}},
             "eig_share_of_step": eig_avg_s / (dt / args.steps), "avg_jacobi_sweeps": sm["avg_sweeps"],
+            "graph_replay": {"value": graph_ips, "unit": "ADMM iters/s", "steps": g_steps, "ms_per_step": 1e3 / graph_ips,
+                             "note": "the mode nnsdp_solve itself runs in (8 iterations per hipGraph replay, no per-launch events); `value` above is the eager rate with HIP events around every projection launch"},
             "graph_replay_iters_per_s": graph_ips, "graph_replay_steps_timed": g_steps,
             "refine_blocks_until_window": sm.get("refine_blocks"),
             "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
         }
         if late:
             fl = flops / (late["kernel_avg_us"] * 1e-6) / 1e12
-            late.update(roofline_frac=fl / FP64_PEAK_TFLOPS, achieved_TFLOPs=fl,
+            late.update(roofline_frac=byts_basis / (late["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, mfma_frac=fl / FP64_PEAK_TFLOPS, achieved_TFLOPs=fl,
                         note="second timed window of the same handle, same K steps and per-launch events; `value` and `roofline` above are the first window")
             out["late_window"] = late
     if rank == 0 and world == 1 and not shard:
@@ -377,7 +387,15 @@ def main():
         out["wide_blocks"] = {"workload": "ACAS-Xu shaped 5-50x6-5 (random weights), reach hyperplane, interval arithmetic, SingleDecomp",
                               "blocks": smw["n_cliques"], "max_block": smw["max_clique"], "burn_in_iters": args.wide_burn_in, "steps": 200,
                               "iters_per_s": 200 / dtw, "kernel_avg_us": 1e3 * msw / 200, "refine_blocks": smw["refine_blocks"],
-                              "note": "one GPU, eager launches with per-launch events like `value`; not BASELINE's metric config"}
+                              "note": "one GPU, eager launches with per-launch events like `value` (the events bracket the five k_pipe_* launches + k_proj_jacobi); not BASELINE's metric config"}
+        if args.cert_seconds > 0:
+            # whole solves of the same query to residuals 1e-5: the reference's cliques, and the decomposition AutoDecomp picks (path cliques 6 x 101)
+            for label, mode in (("single_solve", na.SingleDecomp()), ("auto_decomp_solve", na.AutoDecomp())):
+                t2 = time.perf_counter()
+                s3 = na.runQuery(qw, na.AdmmSdpOptions(decomp_mode=mode, max_iters=300000, eps_rel=1e-5, max_time=args.cert_seconds))
+                out["wide_blocks"][label] = {"wall_s": time.perf_counter() - t2, "solve_s": s3.solve_time, "status": s3.termination_status, "iters": s3.summary["iters"],
+                                             "bound": s3.objective_value, "blocks": s3.summary["n_cliques"], "max_block": s3.summary["max_clique"],
+                                             "lambda_max": s3.summary["lambda_max"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         need = None
         if "time_to_cert" in out:
