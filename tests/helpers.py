@@ -70,3 +70,18 @@ def published_rho(net: str, beta: int):
     """objective values of the OPTIMAL rows the reference published for (net, beta)."""
     return [float(r["obj_val"]) for r in dump_rows()
             if r["net"] == net and int(r["beta"]) == beta and r["term_status"] == "OPTIMAL"]
+
+
+def acas_shaped_query():
+    """BASELINE config 5's shape without its data (no ACAS file is in the reference checkout): a 5-50x6-5 ReLU network with random
+    weights, reach-hyperplane query on a box of half-width 0.05, plain interval arithmetic (no neuron stable, so the reference's Single
+    cliques keep their full 106 + 4 x 151)."""
+    import nnsdp_amd as na
+    from nnsdp_amd import frontend as F
+    net = na.randomNetwork([5] + [50] * 6 + [5], seed=1234)
+    lo, hi = np.full(5, 0.25), np.full(5, 0.35)
+    xi, acx = F.intervalsWorstCase(lo, hi, net)
+    nrm = np.zeros(5)
+    nrm[0] = 1.0
+    return na.ReachQuery(ffnet=net, qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_reach=na.QcReachHplane(normal=nrm),
+                         qc_activs=F.makeQcActivsIntvs(net, xi, acx, 0))

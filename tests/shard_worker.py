@@ -25,8 +25,35 @@ def main():
         calls[0] += 1
         dist.all_reduce(torch.from_numpy(a))      # in place on the library's host buffer
 
-    q = helpers.product_query(helpers.load_problem(name, beta))
+    light = name.endswith(":light")          # BASELINE configs 4 / 5 (W40-D40, the ACAS shape): the plain-iteration leg and a capped solve
+    name = name.split(":")[0]
+    q = helpers.acas_shaped_query() if name == "acas-shape" else helpers.product_query(helpers.load_problem(name, beta))
     res = {"rank": rank}
+    if light:
+        import hashlib
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), proj_refine=0))
+        s.set_comm_callback(world, rank, allreduce)
+        s.iterate(200)
+        res["after_200"] = list(s.residuals())
+        res["mult201_digest"] = hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest()
+        s.close()
+        # the default configuration (stage on; blocks above 96: the tile-parallel pipeline once the stage carries the visits) to an
+        # iteration cap: every decision collective, one certificate
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), eps_rel=1e-6, max_iters=2500, max_time=200))
+        s.set_comm_callback(world, rank, allreduce)
+        sol = s.run()
+        res["capped"] = dict(status=sol.termination_status, iters=int(sol.summary["iters"]), rho=float(sol.objective_value),
+                             lambda_max=float(sol.summary["lambda_max"]), pres=float(sol.summary["pres"]),
+                             gamma=np.concatenate([sol.values[k] for k in ("γin", "γout", "γac1", "γac2")]).tolist())
+        s.close()
+        bn, st = na.shardPlan(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp()), world)
+        res["blocks"] = [int(v) for v in bn]
+        res["blocks_owned"] = [int(st[rank]), int(st[rank + 1])]
+        dist.barrier()
+        dist.destroy_process_group()
+        with open(out, "w") as fh:
+            json.dump(res, fh)
+        return
     # (a) exactly 300 plain iterations, then one check iteration
     # (proj_refine=0 here and in the parent's serial run: the iterates are compared to 1e-8, and the refinement stage's accept /
     # reject thresholds would amplify the 1e-9 difference of the two summation orders; legs (b), (c) run the default)
