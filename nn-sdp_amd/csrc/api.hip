@@ -322,7 +322,8 @@ struct nnsdp_solver {
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
-  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate;
+  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate, d_medrows, d_medsrc;
+  int nmed = 0, nmsrc = 0, nnz_A = 0;     // rows of A with 3 .. kLongRow nonzeros / pattern entries with more than two sources (16 lanes each)
   double refine_acc = 30.0, refine_kcap = 0.05, refine_loose = 1.0;
   int refine_pivots = 2, gram_credit = 3;
   int nlong = 0;
@@ -525,6 +526,16 @@ struct nnsdp_solver {
         if (S.csr_ptr[e + 1] - S.csr_ptr[e] > kLongRow) lr.push_back(e);
       nlong = (int)lr.size();
       d_long.upload(lr);
+      std::vector<int> mr, ms;
+      for (int e = 0; e < S.NE; ++e) {
+        const int nz = S.csr_ptr[e + 1] - S.csr_ptr[e];
+        if (nz > 2 && nz <= kLongRow) mr.push_back(e);
+        if (sptr[e + 1] - sptr[e] > 2) ms.push_back(e);
+      }
+      nmed = (int)mr.size(); nmsrc = (int)ms.size(); nnz_A = std::max(S.csr_ptr[S.NE], 1);
+      if (mr.empty()) mr.push_back(0);
+      if (ms.empty()) ms.push_back(0);
+      d_medrows.upload(mr); d_medsrc.upload(ms);
     }
     // M^-1 on the device (rocSOLVER potrf + potri; one-time plain-library factorisation)
     roc.reset(new RocHandle());
@@ -907,8 +918,9 @@ struct nnsdp_solver {
       allreduce(hsum.p, NE);                      // the overlap-consensus exchange: one all-reduce per iteration
       hipLaunchKernelGGL(k_finish_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, hsum.p, D.z0.p, D.Dinv.p, d_sigma(), g.p);
     } else {
-      hipLaunchKernelGGL(k_gather_g, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr.p, d_soff.p, d_isdiag.p,
-                         nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p);
+      const int nshort = cdiv(NE, kThreads);
+      hipLaunchKernelGGL(k_gather_g, dim3(nshort + cdiv((long long)nmsrc * 16, kThreads)), dim3(kThreads), 0, st, nshort, NE, d_sptr.p, d_soff.p, d_isdiag.p,
+                         nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p, d_medsrc.p, nmsrc);
     }
     hipLaunchKernelGGL(k_spmv_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, D.csc_ptr.p, D.csc_row.p,
                        D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
@@ -925,9 +937,9 @@ struct nnsdp_solver {
     }
     enqueue_minv(st);
     {
-      const int nreg = cdiv((long long)NE * kRowLanes, kThreads);
-      hipLaunchKernelGGL(k_spmv_A_x_all, dim3(nreg + nlong), dim3(kThreads), 0, st, NE, nreg, nlong, d_long.p, D.csr_ptr.p, D.csr_col.p,
-                         D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p);
+      const int nshort = cdiv(NE, kThreads), nreg = nshort + cdiv((long long)nmed * 16, kThreads);
+      hipLaunchKernelGGL(k_spmv_A_x_all, dim3(nreg + nlong), dim3(kThreads), 0, st, NE, nshort, nreg, nlong, d_long.p, D.csr_ptr.p, D.csr_col.p,
+                         D.csr_val.p, ww.p, g.p, D.Dinv.p, x.p, d_medrows.p, nmed, nnz_A);
     }
     if (check)
       hipLaunchKernelGGL(k_check_obj, dim3(nb_obj), dim3(kThreads), 0, st, ng, NE, nu.p, D.c.p, D.z0.p, x.p, d_sigma(), accp.p, acc_stride);
@@ -1506,7 +1518,7 @@ struct nnsdp_batch {
   int nblocks = 0, nmax = 0, alg = 0;
   bool v_lds = true, any_structured = false, any_big = false;
   size_t lds = 0;
-  int gx_gather = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
+  int gx_gather = 0, gx_gather_med = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_ax_med = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   static constexpr int kGraphIters = 8;
@@ -1544,7 +1556,7 @@ struct nnsdp_batch {
     std::vector<IterArgs> it;
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
-    nmax = 0; gx_gather = gx_at = gx_gemv = gx_ax = gx_long = gx_upd = gx_tiles = gx_nb = 0;
+    nmax = 0; gx_gather = gx_gather_med = gx_at = gx_gemv = gx_ax = gx_ax_med = gx_long = gx_upd = gx_tiles = gx_nb = 0;
     any_structured = false; any_big = false;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
@@ -1557,6 +1569,7 @@ struct nnsdp_batch {
       a.csc_ptr = s->D.csc_ptr.p; a.csc_row = s->D.csc_row.p; a.csc_val = s->D.csc_val.p;
       a.csr_ptr = s->D.csr_ptr.p; a.csr_col = s->D.csr_col.p; a.csr_val = s->D.csr_val.p;
       a.longrows = s->d_long.p; a.gidx = s->d_gidx.p;
+      a.medrows = s->d_medrows.p; a.medsrc = s->d_medsrc.p; a.nmed = s->nmed; a.nmsrc = s->nmsrc; a.nnz = s->nnz_A;
       a.z0 = s->D.z0.p; a.Dinv = s->D.Dinv.p; a.c = s->D.c.p; a.Minv = s->Minv.p;
       a.nu = s->nu.p; a.w = s->w.p; a.g = s->g.p; a.p = s->p.p; a.qv = s->qv.p; a.ww = s->ww.p; a.x = s->x.p;
       a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
@@ -1587,10 +1600,12 @@ struct nnsdp_batch {
         for (size_t pos = 0; pos < s->proj_small.size(); ++pos) { map.push_back(make_int2((int)b, (int)pos)); nmax = std::max(nmax, s->cn[s->proj_small[pos]]); }
         any_big = true;
       }
-      gx_gather = std::max(gx_gather, cdiv((long long)a.NE * kGatherLanes, kThreads));
+      gx_gather = std::max(gx_gather, cdiv(a.NE, kThreads));
+      gx_gather_med = std::max(gx_gather_med, cdiv((long long)a.nmsrc * 16, kThreads));
+      gx_ax_med = std::max(gx_ax_med, cdiv((long long)a.nmed * 16, kThreads));
       gx_at = std::max(gx_at, cdiv((long long)a.ng * 64, kThreads));
       gx_gemv = gx_at;
-      gx_ax = std::max(gx_ax, cdiv((long long)a.NE * kRowLanes, kThreads));
+      gx_ax = std::max(gx_ax, cdiv(a.NE, kThreads));
       gx_long = std::max(gx_long, a.nlong);
       gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
     }
@@ -1612,7 +1627,7 @@ struct nnsdp_batch {
     const int B = (int)act.size();
     if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
     if (any_big) for (nnsdp_solver* s : act) s->enqueue_big_blocks(st);
-    hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather + gx_gather_med, B), dim3(kThreads), 0, st, d_it.p, gx_gather);
     hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
     static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic
     if (any_structured) { for (nnsdp_solver* s : act) s->enqueue_minv(st); }     // large multiplier counts: each SDP's structured M^-1
@@ -1621,7 +1636,7 @@ struct nnsdp_batch {
       hipLaunchKernelGGL(k_symv_tiles_b, dim3(gx_tiles, B), dim3(kThreads), 0, st, d_it.p);
       hipLaunchKernelGGL(k_symv_reduce_b, dim3(gx_nb, B), dim3(64), 0, st, d_it.p);
     }
-    hipLaunchKernelGGL(k_spmv_A_x_all_b, dim3(gx_ax + gx_long, B), dim3(kThreads), 0, st, d_it.p, gx_ax);
+    hipLaunchKernelGGL(k_spmv_A_x_all_b, dim3(gx_ax + gx_ax_med + gx_long, B), dim3(kThreads), 0, st, d_it.p, gx_ax, gx_ax_med, 0);
     hipLaunchKernelGGL(k_update_nu_b, dim3(gx_upd, B), dim3(kThreads), 0, st, d_it.p);
     HIPCHK(hipGetLastError());
   }

@@ -2489,6 +2489,7 @@ struct IterArgs {
   const int* csc_ptr; const int* csc_row; const double* csc_val;
   const int* csr_ptr; const int* csr_col; const double* csr_val;
   const int* longrows; const unsigned int* gidx;
+  const int* medrows; const int* medsrc; int nmed, nmsrc, nnz;   // rows of A with 3 .. kLongRow nonzeros / pattern entries with more than 2 sources
   const double* z0; const double* Dinv; const double* c; const double* Minv;
   double* nu; double* w; double* g; double* p; double* qv; double* ww; double* x;
   const double* sigma; double* kappa;
@@ -2508,14 +2509,28 @@ __device__ __forceinline__ void spmv_At_body(const int bid, int ng, const int* _
   int g = (bid * kThreads + threadIdx.x) >> 6;
   int lane = threadIdx.x & 63;
   if (g >= ng) return;
+  // (everything lane 0 needs at the end is requested before the column loop: a dependent round trip less per wave)
+  const double v0 = nus[g], cg = c[g];
+  const double kap = kappa ? *kappa : 1.0;
+  // (a tenth of the columns hold 250 .. 530 nonzeros - the sector multipliers' W' diag W blocks: four chunks of 64 are requested
+  // together, index / value loads first and the gathers behind them, instead of one dependent chain per chunk)
   double s = 0.0;
-  for (int q = ptr[g] + lane; q < ptr[g + 1]; q += 64) s += val[q] * gvec[row[q]];
+  const int q1 = ptr[g + 1];
+  for (int q = ptr[g] + lane; q < q1; q += 256) {
+    double vv[4]; int rr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int qq = min(q + 64 * u, q1 - 1); vv[u] = val[qq]; rr[u] = row[qq]; }
+    double gg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gg[u] = gvec[rr[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (q + 64 * u < q1) ? vv[u] * gg[u] : 0.0;
+  }
   s = wave_sum(s);
   if (lane == 0) {
-    double v = nus[g], wv = v > 0.0 ? v : 0.0;
-    double kap = kappa ? *kappa : 1.0;
+    double v = v0, wv = v > 0.0 ? v : 0.0;
     if (kap != 1.0) { v = wv + kap * (v - wv); nus[g] = v; }
-    double pp = 2.0 * wv - v - c[g];
+    double pp = 2.0 * wv - v - cg;
     p[g] = pp;
     qv[g] = s - pp;
   }
@@ -2540,30 +2555,57 @@ __device__ __forceinline__ double gather_sum(double s) {   // sum over the kGath
   for (int o = 1; o < kGatherLanes; o <<= 1) s += __shfl_xor(s, o, kGatherLanes);
   return s;
 }
-__device__ __forceinline__ void gather_g_body(const int bid, int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
+// Round 4: most pattern entries have ONE source (an element of one clique) or two (an overlap); only the block every clique shares
+// and the overlap strips have more.  Eight lanes per entry for all of them meant 8 x NE threads whose launches, in the batch handle,
+// ran at 1.6 TB/s for want of resident waves (13 SDPs: 11 k workgroups, five rounds of three dependent round trips).  Entries with
+// up to two sources now take ONE thread (blocks [0, nshort)), the others 16 lanes each from a list built at set-up (blocks behind).
+__device__ __forceinline__ void gather_g_body(const int bid, const int nshort, int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
                                                         const unsigned char* __restrict__ isdiag,
                                                         const double* __restrict__ nuk, const double* __restrict__ wk,
                                                         const double* __restrict__ z0, const double* __restrict__ Dinv,
-                                                        const double* __restrict__ sigma, double* __restrict__ g) {
-  const int t = bid * kThreads + threadIdx.x;
-  const int e = t / kGatherLanes, sub = t % kGatherLanes;
-  if (e >= NE) return;   // (the lanes of one entry leave together)
+                                                        const double* __restrict__ sigma, double* __restrict__ g,
+                                                        const int* __restrict__ medsrc, const int nmsrc) {
+  if (bid < nshort) {
+    const int e = bid * kThreads + threadIdx.x;
+    if (e >= NE) return;
+    const int p0 = sptr[e], ns = sptr[e + 1] - p0;
+    const double zz = z0[e], dd = Dinv[e], sg = *sigma;
+    const bool dg = isdiag[e] != 0;
+    if (ns > 2) return;
+    // (both source slots are read whatever ns is - clamped, masked afterwards: no load waits behind a branch)
+    const long long o0 = soff[p0], o1 = soff[p0 + (ns > 1 ? 1 : 0)];
+    const double a0 = 2.0 * wk[o0] - nuk[o0], a1 = 2.0 * wk[o1] - nuk[o1];
+    double s = (ns > 0 ? a0 : 0.0) + (ns > 1 ? a1 : 0.0);
+    if (!dg) s *= kSqrt2;
+    g[e] = dd * (zz / sg + s);
+    return;
+  }
+  const int t = (bid - nshort) * kThreads + threadIdx.x;
+  const int r = t >> 4, sub = t & 15;
+  if (r >= nmsrc) return;   // (the lanes of one entry leave together)
+  const int e = medsrc[r];
   double s = 0.0;
-  for (int q = sptr[e] + sub; q < sptr[e + 1]; q += kGatherLanes) { long long o = soff[q]; s += 2.0 * wk[o] - nuk[o]; }
-  s = gather_sum(s);
+  for (int q = sptr[e] + sub; q < sptr[e + 1]; q += 16) { long long o = soff[q]; s += 2.0 * wk[o] - nuk[o]; }
+  s = row_sum16(s);
   if (sub != 0) return;
   if (!isdiag[e]) s *= kSqrt2;
   g[e] = Dinv[e] * (z0[e] / (*sigma) + s);
 }
-__global__ __launch_bounds__(kThreads) void k_gather_g(int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
+__global__ __launch_bounds__(kThreads) void k_gather_g(int nshort, int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
                                                         const unsigned char* __restrict__ isdiag,
                                                         const double* __restrict__ nuk, const double* __restrict__ wk,
                                                         const double* __restrict__ z0, const double* __restrict__ Dinv,
-                                                        const double* __restrict__ sigma, double* __restrict__ g) { gather_g_body(blockIdx.x, NE, sptr, soff, isdiag, nuk, wk, z0, Dinv, sigma, g); }
-__global__ __launch_bounds__(kThreads) void k_gather_g_b(const IterArgs* __restrict__ A) {
+                                                        const double* __restrict__ sigma, double* __restrict__ g,
+                                                        const int* __restrict__ medsrc, int nmsrc) { gather_g_body(blockIdx.x, nshort, NE, sptr, soff, isdiag, nuk, wk, z0, Dinv, sigma, g, medsrc, nmsrc); }
+// batch handles: blocks [0, nshort_max) one thread per entry, blocks behind 16 lanes per listed entry (every member leaves the blocks
+// past its own counts at once)
+__global__ __launch_bounds__(kThreads) void k_gather_g_b(const IterArgs* __restrict__ A, int nshort_max) {
   const IterArgs a = A[blockIdx.y];
-  if ((long long)blockIdx.x * kThreads >= (long long)a.NE * kGatherLanes) return;
-  gather_g_body(blockIdx.x, a.NE, a.sptr, a.soff, a.isdiag, a.nu + a.ng, a.w + a.ng, a.z0, a.Dinv, a.sigma, a.g);
+  const int mine = (a.NE + kThreads - 1) / kThreads;
+  int bid = blockIdx.x;
+  if (bid < nshort_max) { if (bid >= mine) return; }
+  else { bid = bid - nshort_max + mine; if ((long long)(bid - mine) * kThreads >= (long long)a.nmsrc * 16) return; }
+  gather_g_body(bid, mine, a.NE, a.sptr, a.soff, a.isdiag, a.nu + a.ng, a.w + a.ng, a.z0, a.Dinv, a.sigma, a.g, a.medsrc, a.nmsrc);
 }
 
 // clique-sharded mode: h[e] = wgt * sum over the rank's OWN sources of (2 w - nu), or of (nu - w) when dual != 0;
@@ -2707,28 +2749,45 @@ __global__ __launch_bounds__(64) void k_symv_reduce_b(const IterArgs* __restrict
 // multiplier at all and 37 % with one; only 2 880 rows carry more than 16 nonzeros)
 static constexpr int kRowLanes = 8;
 static constexpr int kLongRow = 256;   // rows of A with more nonzeros go to the block-per-row kernel
-__device__ __forceinline__ void spmv_A_x_body(const int bid, int NE, const int* __restrict__ ptr, const int* __restrict__ col,
+// Round 4: 60 % of the rows of A have no multiplier at all and 37 % one (W40-D20); rows with up to two nonzeros take ONE thread
+// (blocks [0, nshort)), rows with 3 .. kLongRow nonzeros 16 lanes each from a list built at set-up (the first form gave every row 8
+// lanes: 8 x NE threads per SDP, and the batched launch ran at 0.6 TB/s - resident-wave-bound, five rounds of dependent round trips)
+__device__ __forceinline__ void spmv_A_x_body(const int bid, const int nshort, int NE, const int* __restrict__ ptr, const int* __restrict__ col,
                                                         const double* __restrict__ val, const double* __restrict__ ww,
                                                         const double* __restrict__ g, const double* __restrict__ Dinv,
-                                                        double* __restrict__ x) {
-  int e = (bid * kThreads + threadIdx.x) / kRowLanes;
-  int sub = threadIdx.x & (kRowLanes - 1);
+                                                        double* __restrict__ x, const int* __restrict__ medrows, const int nmed, const int nnz) {
+  if (bid < nshort) {
+    const int e = bid * kThreads + threadIdx.x;
+    if (e >= NE) return;
+    const int p0 = ptr[e], n = ptr[e + 1] - p0;
+    const double ge = g[e], de = Dinv[e];
+    if (n > 2) return;
+    // (both slots read whatever n is - clamped into the table, masked afterwards)
+    const int q0 = min(p0, nnz - 1), q1 = min(p0 + 1, nnz - 1);
+    const double t0 = val[q0] * ww[col[q0]], t1 = val[q1] * ww[col[q1]];
+    const double s = (n > 0 ? t0 : 0.0) + (n > 1 ? t1 : 0.0);
+    x[e] = ge - de * s;
+    return;
+  }
+  const int t = (bid - nshort) * kThreads + threadIdx.x;
+  const int r = t >> 4, sub = t & 15;
+  if (r >= nmed) return;
+  const int e = medrows[r];
+  const double ge = g[e], de = Dinv[e];
   double s = 0.0;
-  bool mine = e < NE && ptr[e + 1] - ptr[e] <= kLongRow;
-  if (mine)
-    for (int q = ptr[e] + sub; q < ptr[e + 1]; q += kRowLanes) s += val[q] * ww[col[q]];
+  const int q1 = ptr[e + 1];
+  for (int q = ptr[e] + sub; q < q1; q += 64) {      // (four chunks of 16 in flight)
+    double vv[4]; int cc[4];
 #pragma unroll
-  for (int o = kRowLanes / 2; o > 0; o >>= 1) s += __shfl_down(s, o, kRowLanes);
-  if (mine && sub == 0) x[e] = g[e] - Dinv[e] * s;
-}
-__global__ __launch_bounds__(kThreads) void k_spmv_A_x(int NE, const int* __restrict__ ptr, const int* __restrict__ col,
-                                                        const double* __restrict__ val, const double* __restrict__ ww,
-                                                        const double* __restrict__ g, const double* __restrict__ Dinv,
-                                                        double* __restrict__ x) { spmv_A_x_body(blockIdx.x, NE, ptr, col, val, ww, g, Dinv, x); }
-__global__ __launch_bounds__(kThreads) void k_spmv_A_x_b(const IterArgs* __restrict__ A) {
-  const IterArgs a = A[blockIdx.y];
-  if ((long long)blockIdx.x * kThreads >= (long long)a.NE * kRowLanes) return;
-  spmv_A_x_body(blockIdx.x, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+    for (int u = 0; u < 4; ++u) { const int qq = min(q + 16 * u, q1 - 1); vv[u] = val[qq]; cc[u] = col[qq]; }
+    double xx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xx[u] = ww[cc[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (q + 16 * u < q1) ? vv[u] * xx[u] : 0.0;
+  }
+  s = row_sum16(s);
+  if (sub == 0) x[e] = ge - de * s;
 }
 
 // the few long rows (the affine-affine entry touches every multiplier): one workgroup per row
@@ -2738,10 +2797,21 @@ __device__ __forceinline__ void spmv_A_x_long_body(const int bid, int nlong, con
                                                              const double* __restrict__ Dinv, double* __restrict__ x) {
   __shared__ double red[8];
   int e = rows[bid];
+  const double ge = g[e], de = Dinv[e];
   double s = 0.0;
-  for (int q = ptr[e] + threadIdx.x; q < ptr[e + 1]; q += kThreads) s += val[q] * ww[col[q]];
+  const int q1 = ptr[e + 1];
+  for (int q = ptr[e] + threadIdx.x; q < q1; q += 8 * kThreads) {      // (eight chunks in flight: the affine-affine row touches every multiplier)
+    double vv[8]; int cc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int qq = min(q + kThreads * u, q1 - 1); vv[u] = val[qq]; cc[u] = col[qq]; }
+    double xx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xx[u] = ww[cc[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (q + kThreads * u < q1) ? vv[u] * xx[u] : 0.0;
+  }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) x[e] = g[e] - Dinv[e] * s;
+  if (threadIdx.x == 0) x[e] = ge - de * s;
 }
 __global__ __launch_bounds__(kThreads) void k_spmv_A_x_long(int nlong, const int* __restrict__ rows, const int* __restrict__ ptr,
                                                              const int* __restrict__ col, const double* __restrict__ val,
@@ -2753,24 +2823,33 @@ __global__ __launch_bounds__(kThreads) void k_spmv_A_x_long_b(const IterArgs* __
   spmv_A_x_long_body(blockIdx.x, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
 }
 
-// both forms in one launch: blocks [0, nreg) take the short rows 4 lanes each, blocks [nreg, nreg + nlong) one long row each
-__global__ __launch_bounds__(kThreads) void k_spmv_A_x_all(int NE, int nreg, int nlong, const int* __restrict__ rows,
+// all forms in one launch: blocks [0, nshort) one thread per row (rows with up to two nonzeros), [nshort, nreg) 16 lanes per listed
+// medium row, [nreg, nreg + nlong) one workgroup per long row
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_all(int NE, int nshort, int nreg, int nlong, const int* __restrict__ rows,
                                                             const int* __restrict__ ptr, const int* __restrict__ col,
                                                             const double* __restrict__ val, const double* __restrict__ ww,
                                                             const double* __restrict__ g, const double* __restrict__ Dinv,
-                                                            double* __restrict__ x) {
-  if ((int)blockIdx.x < nreg) spmv_A_x_body(blockIdx.x, NE, ptr, col, val, ww, g, Dinv, x);
+                                                            double* __restrict__ x, const int* __restrict__ medrows, int nmed, int nnz) {
+  if ((int)blockIdx.x < nreg) spmv_A_x_body(blockIdx.x, nshort, NE, ptr, col, val, ww, g, Dinv, x, medrows, nmed, nnz);
   else spmv_A_x_long_body(blockIdx.x - nreg, nlong, rows, ptr, col, val, ww, g, Dinv, x);
 }
-__global__ __launch_bounds__(kThreads) void k_spmv_A_x_all_b(const IterArgs* __restrict__ A, int nreg_max) {
+// batch handles: [0, nshort_max) short rows, [nshort_max, nshort_max + nmedb_max) medium rows, behind them the long rows
+__global__ __launch_bounds__(kThreads) void k_spmv_A_x_all_b(const IterArgs* __restrict__ A, int nshort_max, int nmedb_max, int nnz_dummy) {
   const IterArgs a = A[blockIdx.y];
-  if ((int)blockIdx.x < nreg_max) {
-    if ((long long)blockIdx.x * kThreads >= (long long)a.NE * kRowLanes) return;
-    spmv_A_x_body(blockIdx.x, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+  const int mine = (a.NE + kThreads - 1) / kThreads;
+  const int b = blockIdx.x;
+  (void)nnz_dummy;
+  if (b < nshort_max) {
+    if (b >= mine) return;
+    spmv_A_x_body(b, mine, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x, a.medrows, a.nmed, a.nnz);
+  } else if (b < nshort_max + nmedb_max) {
+    const int bm = b - nshort_max;
+    if ((long long)bm * kThreads >= (long long)a.nmed * 16) return;
+    spmv_A_x_body(mine + bm, mine, a.NE, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x, a.medrows, a.nmed, a.nnz);
   } else {
-    const int b = blockIdx.x - nreg_max;
-    if (b >= a.nlong) return;
-    spmv_A_x_long_body(b, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
+    const int bl = b - nshort_max - nmedb_max;
+    if (bl >= a.nlong) return;
+    spmv_A_x_long_body(bl, a.nlong, a.longrows, a.csr_ptr, a.csr_col, a.csr_val, a.ww, a.g, a.Dinv, a.x);
   }
 }
 
