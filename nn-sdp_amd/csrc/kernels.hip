@@ -112,6 +112,7 @@ struct ProjArgs {
   int gram_credit;        // visits a block may run without the Gram product after a visit that measured it (0 .. 15)
   int refine_pivots;      // exact rotations of the dominant pair first order cannot resolve, per visit (0 = off)
   double refine_loose;    // >= 1: the one-off acceptance level of an isolated near miss, as a multiple of refine_acc (1 = off)
+  double refine_k2cap;    // a step is only taken when |K|_F^2 is below this (0.09: |K|_F <= 0.3; see api.hip, refine_k2cap)
   int max_sweeps;
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
   const int* pmode;       // per block, may be null: != 0 = the tile-parallel pipeline launched in front (refine_pipe.hpp) has already
@@ -886,7 +887,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
           const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);    // rebuilding from the positive / negative side
           const bool prefer_pos = cpos <= cneg;
-          const bool kok = k2 <= 0.09;      // |K|_F <= 0.3: the step is a rotation to |K|^3 / 6 < 5e-3 whatever the eigenvalues it touches
+          const bool kok = k2 <= a.refine_k2cap;      // |K|_F <= 0.3: the step is a rotation to |K|^3 / 6 < 5e-3 whatever the eigenvalues it touches
           if (kok && (prefer_pos ? pred_pos : pred_neg) <= accT) side_force = prefer_pos ? 1 : -1;
           else if (kok && (prefer_pos ? pred_neg : pred_pos) <= accT) side_force = prefer_pos ? -1 : 1;
           // an isolated near miss: a block that took the step at the regular level on its last 16 visits may take ONE step whose prediction
@@ -895,7 +896,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           else if (kok && credit >= 16 && fmin(pred_pos, pred_neg) <= a.refine_loose * accT) { side_force = pred_pos <= pred_neg ? 1 : -1; loose = true; }
           // (the checked form needs a step that is a rotation at all: |K|_F <= 0.3 keeps V (I + X) orthogonal to |K|^3 / 6 < 5e-3,
           // which the Newton-Schulz repair below takes back if the check then fails)
-          else check = rmode >= 2 && k2 <= 0.09 && fmin(pred_pos, pred_neg) <= 30.0 * accT;
+          else check = rmode >= 2 && k2 <= a.refine_k2cap && fmin(pred_pos, pred_neg) <= 30.0 * accT;
           far = fmin(pred_pos, pred_neg) > 10.0 * accT;
         }
       };
@@ -925,7 +926,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       // of V, the pair's rows of B (lower triangle: the strict upper tiles still hold the first product of the congruence); B and V
       // stay consistent - and look again (at most refine_pivots times; Gram product and analysis only).
       int pivots = 0;
-      if (__builtin_expect(!refined && side_force == 0 && r2 <= 1e-4 && k2 <= 0.09 && unx > 0.0 && a.refine_pivots > 0, 0)) {
+      if (__builtin_expect(!refined && side_force == 0 && r2 <= 1e-4 && k2 <= a.refine_k2cap && unx > 0.0 && a.refine_pivots > 0, 0)) {
         for (;;) {
           // the largest coupling that counts against both sides
           double pm = 0.0;
@@ -984,7 +985,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           }
           analyse();
           decide();
-          if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= 0.09) || !(unx > 0.0)) break;
+          if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= a.refine_k2cap) || !(unx > 0.0)) break;
         }
       }
       if (side_force == 0 && !refined && r2 <= 1e-4 && tid == 0 && a.stats) {      // diagnostic: which term of the prediction rejected the block
@@ -1278,7 +1279,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
         cneg = uniform(block_sum((tid < n && dvec[tid] < 0.0) ? 1.0 : 0.0, red));
         __syncthreads();
         if (off2 <= T * T && r2 <= tolv * tolv) { outcome = 0; refined = true; }
-        else if (r2 <= 1e-4 && k2 <= 0.09) {
+        else if (r2 <= 1e-4 && k2 <= a.refine_k2cap) {
           pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0) + sqrt(r2) * sqrt(fro2);   // (an uncorrected defect shows in the projection to first order)
           const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);
           const bool prefer_pos = cpos <= cneg;
@@ -1292,7 +1293,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
       // the one pair across zero that first order cannot resolve (see the ping-pong form): rotated exactly - its two rows of the packed
       // B, its two columns of V in HBM - and the block analysed again, at most refine_pivots times
       int pivots = 0;
-      if (__builtin_expect(!refined && side_force == 0 && r2 <= 1e-4 && k2 <= 0.09 && unx > 0.0 && a.refine_pivots > 0, 0)) {
+      if (__builtin_expect(!refined && side_force == 0 && r2 <= 1e-4 && k2 <= a.refine_k2cap && unx > 0.0 && a.refine_pivots > 0, 0)) {
         for (;;) {
           double pm = 0.0;
           int pidx = 0;
@@ -1332,7 +1333,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
           __syncthreads();
           ++pivots;
           pk_analyse();
-          if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= 0.09) || !(unx > 0.0)) break;
+          if (pivots >= a.refine_pivots || refined || side_force != 0 || !(r2 <= 1e-4) || !(k2 <= a.refine_k2cap) || !(unx > 0.0)) break;
         }
       }
       if (side_force != 0) {

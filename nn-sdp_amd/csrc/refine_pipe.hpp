@@ -67,7 +67,7 @@ struct PipeArgs {
   const double* kappa;      // device scalar, may be null
   const double* tol_dev;    // device scalar, may be null
   double tol;
-  double refine_acc, refine_kcap, refine_loose;
+  double refine_acc, refine_kcap, refine_loose, refine_k2cap;
   int gram_credit;
   int vs;                   // stride of the per-block vectors (multiple of 16, >= largest block)
   int pt;                   // stride of psum in tiles (>= lower tiles of the largest block)
@@ -94,9 +94,10 @@ struct PipeDecision {
   bool loose, do_gram;
   double r2, k2, rdef;
   int credit, gcred;
+  double off2, unpp, unnn, unx, kd2, accT;      // (diagnostics: the terms of the prediction)
 };
-// decision record written by P3's first wave for P4 / P5
-struct PipeRec { int mode, up, loose, do_gram, credit, gcred; double r2, k2, rdef; };
+// decision record written by P3's first wave for P4 / P5 (the tail is diagnostic: NNSDP_PIPE_DEBUG prints it at finish)
+struct PipeRec { int mode, up, loose, do_gram, credit, gcred; double r2, k2, rdef; double off2, unpp, unnn, unx, kd2, accT; };
 
 // diag(V'AV)_j from the row groups' partial sums (fixed order).  Both slots are read whatever the block's group count (the unused
 // one stays zero): a loop over a run-time count makes every call a load - wait - add sequence, and the kernels' prologues call this
@@ -119,6 +120,7 @@ __device__ __forceinline__ PipeDecision pipe_decide(const PipeArgs& a, const int
   D.rdef = *reinterpret_cast<const double*>(a.vrec + 4 * b + 2);
   D.credit = (rs >> 16) & 255; D.gcred = (rs >> 24) & 15;
   D.mode = 0; D.up = true; D.loose = false; D.r2 = 0.0; D.k2 = 0.0;
+  D.off2 = D.unpp = D.unnn = D.unx = D.kd2 = D.accT = 0.0;
   if ((rs & 255) != 0) return D;                       // back-off: not attempted
   double s[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int t = lane; t < ntl; t += 64) {
@@ -145,13 +147,14 @@ __device__ __forceinline__ PipeDecision pipe_decide(const PipeArgs& a, const int
   const double off2 = s[0], k2 = s[1], unpp = s[2], unnn = s[3], unx = s[4], kd2 = s[5];
   const double r2 = D.do_gram ? s[6] : D.rdef * D.rdef;
   D.r2 = r2; D.k2 = k2;
+  D.off2 = off2; D.unpp = unpp; D.unnn = unnn; D.unx = unx; D.kd2 = kd2; D.accT = accT;
   D.up = cpos <= cneg;
   if (off2 <= Tl * Tl && r2 <= tolv * tolv) { D.mode = 2; return D; }
   if (r2 <= 1e-4) {
     const double pred0 = 1.5 * sqrt(off2) * sqrt(k2) + k2 * sqrt(kd2) * (1.0 / 3.0);
     const double pred_pos = pred0 + sqrt(unpp + unx), pred_neg = pred0 + sqrt(unnn + unx);
     const bool prefer_pos = cpos <= cneg;
-    const bool kok = k2 <= 0.09;
+    const bool kok = k2 <= a.refine_k2cap;
     int side = 0;
     if (kok && (prefer_pos ? pred_pos : pred_neg) <= accT) side = prefer_pos ? 1 : -1;
     else if (kok && (prefer_pos ? pred_neg : pred_pos) <= accT) side = prefer_pos ? -1 : 1;
@@ -525,6 +528,7 @@ __global__ __launch_bounds__(64 * kPipeWaves) void k_pipe_X(PipeArgs a) {
   if (writer && lane == 0) {
     rec->mode = D.mode; rec->up = D.up ? 1 : 0; rec->loose = D.loose ? 1 : 0; rec->do_gram = D.do_gram ? 1 : 0;
     rec->credit = D.credit; rec->gcred = D.gcred; rec->r2 = D.r2; rec->k2 = D.k2; rec->rdef = D.rdef;
+    rec->off2 = D.off2; rec->unpp = D.unpp; rec->unnn = D.unnn; rec->unx = D.unx; rec->kd2 = D.kd2; rec->accT = D.accT;
   }
   if (D.mode != 1) return;                 // (uniform over the workgroup)
   pipe_strip_store(pe, G, SE, n, 16 * tj);
@@ -840,7 +844,7 @@ struct RefinePipe {
     auto al = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) e = hipMemset(*p, 0, bytes ? bytes : 8); } };
     al((void**)&wgmap, map.size() * sizeof(PipeWg));
     al((void**)&T, ((size_t)nmat + 16) * 8); al((void**)&E, ((size_t)nmat + 16) * 8); al((void**)&U, ((size_t)nmat + 16) * 8);
-    al((void**)&Vt, ((size_t)nmat + 16) * 8); al((void**)&Et, ((size_t)nmat + 16) * 8); al((void**)&drec, (size_t)nb * 64);
+    al((void**)&Vt, ((size_t)nmat + 16) * 8); al((void**)&Et, ((size_t)nmat + 16) * 8); al((void**)&drec, (size_t)nb * sizeof(PipeRec));
     al((void**)&dpart, (size_t)nb * kMaxGroups * vs * 8); al((void**)&rdg, (size_t)nb * vs * 8); al((void**)&lpart, (size_t)nb * kMaxGroups * vs * 4 * 8);
     al((void**)&frop, (size_t)nb * 16 * 8); al((void**)&psum, (size_t)nb * pt * 8 * 8);
     al((void**)&vrec, (size_t)nb * 4 * sizeof(int)); al((void**)&pmode, (size_t)nb * sizeof(int));
@@ -859,7 +863,7 @@ struct RefinePipe {
     a.T = T; a.E = E; a.U = U; a.Vt = Vt; a.Et = Et; a.drec = drec; a.dpart = dpart; a.rdg = rdg; a.lpart = lpart; a.frop = frop; a.psum = psum;
     a.vrec = vrec; a.pmode = pmode;
     a.rstate = p.rstate; a.stats = p.stats; a.kappa = p.kappa; a.tol_dev = p.tol_dev; a.tol = p.tol;
-    a.refine_acc = p.refine_acc; a.refine_kcap = p.refine_kcap; a.refine_loose = p.refine_loose; a.gram_credit = p.gram_credit;
+    a.refine_acc = p.refine_acc; a.refine_kcap = p.refine_kcap; a.refine_loose = p.refine_loose; a.refine_k2cap = p.refine_k2cap; a.gram_credit = p.gram_credit;
     a.vs = vs; a.pt = pt; a.rows = rows; a.eig = p.eig; a.eoff = p.eoff;
     return a;
   }

@@ -8,8 +8,11 @@ for p in (ROOT, os.path.join(ROOT, "nn-sdp_amd"), os.path.join(ROOT, "tests")):
 import numpy as np
 import nnsdp_amd as na
 from oracle import nnet_io                  # (only the random network of tests/test_gpu_parity.py's 151-block case: weights, nothing else)
-onet = nnet_io.random_net([5] + [50] * 6 + [5], seed=1)
-net = na.FeedFwdNet(xdims=onet.xdims, Ms=onet.Ms)
+if len(sys.argv) > 1 and sys.argv[1] == "bench":      # the network of bench.py's wide_blocks leg
+    net = na.randomNetwork([5] + [50] * 6 + [5], seed=1234)
+else:
+    onet = nnet_io.random_net([5] + [50] * 6 + [5], seed=1)
+    net = na.FeedFwdNet(xdims=onet.xdims, Ms=onet.Ms)
 x0 = np.full(5, 0.3)
 lo, hi = x0 - 0.05, x0 + 0.05
 from nnsdp_amd import frontend as F
@@ -17,7 +20,7 @@ xi, acx = F.intervalsWorstCase(lo, hi, net)       # (plain interval arithmetic: 
 qa = F.makeQcActivsIntvs(net, xi, acx, 0)
 nrm = np.zeros(5); nrm[0] = 1.0
 q = na.ReachQuery(ffnet=net, qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_reach=na.QcReachHplane(normal=nrm), qc_activs=qa)
-for rf in (0, 1):
+for rf in ((1,) if len(sys.argv) > 1 else (0, 1)):
     t = time.time()
     s = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=200000, eps_rel=1e-5, max_time=60, proj_refine=rf))
     print(f"5-50x6-5 reach hyperplane, Single (max block {s.summary['max_clique']}), proj_refine {rf}: {s.termination_status} bound {s.objective_value:.7f} iters {s.summary['iters']} "
@@ -28,7 +31,7 @@ for rf in (0, 1):
 slv = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9, proj_refine=1))
 prev = [0] * 5
 done = 0
-for upto in range(2000, 22001, 2000):
+for upto in range(2000, 20001, 2000):
     t = time.time()
     slv.advance(upto - done); done = upto
     dt = time.time() - t
