@@ -84,7 +84,7 @@ typedef struct nnsdp_options {
   int32_t normalize;      /* 1: solver-internal interval congruence + fixed-neuron elimination (reach queries) (default) */
   int32_t warm_start;     /* 1: warm-start each eigendecomposition from the previous eigenvectors */
   double proj_tol;        /* Jacobi stops at off(A) <= proj_tol |A|_F; 0 = adaptive: 0.01 x the current residual,
-                             clamped to [1e-9, 1e-3] (inexact projections well below the residual level) */
+                             clamped to [1e-9, 1e-4] (inexact projections well below the residual level) */
   int32_t polish;         /* 1: make the returned (gamma, Z) exactly feasible (diagonal shift + Schur complement for gout) */
   double cert_tol;        /* > 0 (reach queries): also stop once the polished, exactly feasible objective is within
                              cert_tol (relative) of the ADMM primal/dual objective estimates; 0 = residual test only.

@@ -349,8 +349,9 @@ def test_solver_with_the_pipeline_agrees(pipe, monkeypatch):
     monkeypatch.setenv("NNSDP_PIPE", pipe)
     on = na.runQuery(q, na.AdmmSdpOptions(**opts))
     assert on.termination_status == off.termination_status == "OPTIMAL"
-    assert abs(on.summary["objective_admm"] - off.summary["objective_admm"]) <= 2e-5 * abs(off.summary["objective_admm"])
-    assert abs(on.objective_value - off.objective_value) <= 1e-5 * abs(off.objective_value)
+    lvl = 20 * opts["eps_rel"]      # (two runs to the same residual level agree in the objective at a small multiple of that level)
+    assert abs(on.summary["objective_admm"] - off.summary["objective_admm"]) <= lvl * abs(off.summary["objective_admm"])
+    assert abs(on.objective_value - off.objective_value) <= lvl * abs(off.objective_value)
     assert abs(on.summary["iters"] - off.summary["iters"]) <= 0.25 * off.summary["iters"]
     assert on.summary["lambda_max"] <= 1e-7
     print("solve seconds with / without the pipeline:", on.solve_time, off.solve_time, "block visits", on.summary["refine_blocks"])

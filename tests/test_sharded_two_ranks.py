@@ -120,7 +120,10 @@ def test_two_rank_sharded_baseline_configs_4_and_5(name, tmp_path):
     r0, r1 = (json.load(open(o)) for o in outs)
     # (the consensus sum is associated differently in the two modes; on the 151-wide blocks the inexact sweeps of the first hundred
     # iterations - stopped at the adaptive tolerance, 1e-4 this early - turn that 1e-16 into a difference at their own level)
-    rtol = 2e-3 if name == "acas-shape" else 1e-7
+    # W40-D40: the serial run's M^-1 comes from this process's own rocSOLVER call, the ranks' from rank 0's - under three-process
+    # contention those differ in the last bits one run in three (profiles/r03_contention_repro_minv_digest.log),
+    # and 200 iterations of this collapsed network turn that into 4e-7; the two RANKS stay bit-identical (asserted below)
+    rtol = 2e-3 if name == "acas-shape" else 1e-5
     for r in (r0, r1):
         assert np.allclose(r["after_200"], ref200, rtol=rtol, atol=1e-12), (r["after_200"], ref200)
     assert r0["after_200"] == r1["after_200"] and r0["mult201_digest"] == r1["mult201_digest"]
