@@ -296,6 +296,14 @@ int nnsdp_solver_set_comm(nnsdp_solver* s, int32_t nranks, int32_t rank, const c
  * memory for it; partition, kernels and the collective control decisions are those of nnsdp_solver_set_comm. */
 typedef int (*nnsdp_allreduce_fn)(void* user, double* buf, int64_t count);
 int nnsdp_solver_set_comm_callback(nnsdp_solver* s, int32_t nranks, int32_t rank, nnsdp_allreduce_fn fn, void* user);
+/* The sharded mode with a DEVICE-SIDE exchange for ranks that are processes of one node (one card, or peers over xGMI; at most 8):
+ * every rank's exchange buffer is mapped into the others' address space with hipIpc, and the per-iteration exchange is a one-shot
+ * all-gather + local reduce in rank order by the library's own kernels (slot of the rank's buffer, exchange number published behind a
+ * system-scope release, bounded spin on the peers' numbers) - no library collective in the iteration, the same bits on every rank,
+ * capturable into the iteration's hipGraph.  fn is used as in nnsdp_solver_set_comm_callback for the set-up (the 64-byte handles) and
+ * for the control decisions of the check iterations.  A peer that does not publish within a few seconds fails the next check
+ * iteration with an error instead of hanging the device.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only supports dmabuf. */
+int nnsdp_solver_set_comm_ipc(nnsdp_solver* s, int32_t nranks, int32_t rank, nnsdp_allreduce_fn fn, void* user);
 
 #ifdef __cplusplus
 }

@@ -392,9 +392,17 @@ struct nnsdp_solver {
   DBuf<int> d_sptr_own;
   DBuf<long long> d_soff_own;
   DBuf<double> hsum;
+  // device-side transport of the sharded mode (hipIpc-mapped peer buffers, kernels.hip: k_ipc_publish / k_ipc_reduce)
+  bool ipc = false;
+  DBuf<double> xbuf;                    // [2][NE] slots + 2 flag words
+  DBuf<unsigned long long> ipc_ctr;
+  DBuf<int> ipc_err;
+  nnsdp::IpcArgs ipa{};
+  std::vector<void*> ipc_opened;
 
   ~nnsdp_solver() {
     if (comm) (void)Rccl::get().CommDestroy(comm);
+    for (void* q : ipc_opened) (void)hipIpcCloseMemHandle(q);
     for (hipGraphExec_t g : gexec_chk) if (g) (void)hipGraphExecDestroy(g);
     if (acc_host) (void)hipHostFree(acc_host);
     if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -750,8 +758,9 @@ struct nnsdp_solver {
     else hipLaunchKernelGGL(k_gemv_sym, dim3(cdiv((long long)S.ng * 64, kThreads)), dim3(kThreads), 0, s_, S.ng, ldm, Minv.p, qv.p, ww.p);
   }
 
-  void set_comm(int nr, int rk, const char* id128, nnsdp_allreduce_fn fn = nullptr, void* user = nullptr) {
+  void set_comm(int nr, int rk, const char* id128, nnsdp_allreduce_fn fn = nullptr, void* user = nullptr, bool use_ipc = false) {
     if (nr < 1 || rk < 0 || rk >= nr || (!id128 && !fn)) throw std::invalid_argument("bad communicator arguments");
+    if (use_ipc && (!fn || nr > 8)) throw std::invalid_argument("the hipIpc transport needs the caller's host all-reduce for its set-up and at most 8 ranks");
     if (iters_done != 0) throw std::invalid_argument("set_comm must be called before the first iteration");
     if (sharded) throw std::invalid_argument("the solver already has a communicator");
     if (fn) { ar_fn = fn; ar_user = user; }
@@ -781,6 +790,35 @@ struct nnsdp_solver {
     d_sptr_own.upload(sp2); d_soff_own.upload(so2);
     hsum.alloc(S.NE);
     hsum.zero();
+    if (use_ipc) {
+      // every rank maps every other rank's exchange buffer: the 64-byte hipIpc handles travel once through the caller's host
+      // all-reduce (one byte per double: a sum of zeros and one value is exact whatever the bit pattern)
+      xbuf.alloc(2 * (size_t)S.NE + 4); xbuf.zero();
+      ipc_ctr.alloc(1); ipc_ctr.zero(); ipc_err.alloc(1); ipc_err.zero();
+      hipIpcMemHandle_t mine;
+      HIPCHK(hipIpcGetMemHandle(&mine, xbuf.p));
+      static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpc handle size");
+      std::vector<double> all((size_t)nr * 64, 0.0);
+      const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mine);
+      for (int i = 0; i < 64; ++i) all[(size_t)rk * 64 + i] = (double)mb[i];
+      if (fn(user, all.data(), (int64_t)all.size()) != 0) throw std::runtime_error("the caller's all-reduce reported a failure");
+      ipa = nnsdp::IpcArgs{};
+      ipa.nranks = nr; ipa.rank = rk; ipa.NE = S.NE; ipa.ctr = ipc_ctr.p; ipa.err = ipc_err.p;
+      ipa.spin_limit = 4000000;      // (a few seconds: ranks reach their first exchange a set-up time apart)
+      if (const char* e = std::getenv("NNSDP_IPC_SPIN_LIMIT")) ipa.spin_limit = std::atoll(e);
+      for (int r = 0; r < nr; ++r) {
+        if (r == rk) { ipa.peer[r] = xbuf.p; continue; }
+        hipIpcMemHandle_t h;
+        unsigned char* hb = reinterpret_cast<unsigned char*>(&h);
+        for (int i = 0; i < 64; ++i) hb[i] = (unsigned char)all[(size_t)r * 64 + i];
+        void* q = nullptr;
+        HIPCHK(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+        ipc_opened.push_back(q);
+        ipa.peer[r] = static_cast<double*>(q);
+      }
+      ipc = true;
+      rccl_graph_ok = true;          // (kernels only: the exchange replays inside the iteration's hipGraph like any other launch)
+    }
     // The Woodbury core is built per process by rocSOLVER / rocBLAS, and those do not return the same bits every time when several
     // processes share a card (1 set-up in 20 under three-process contention, profiles/r03_contention_repro.log: every deviating
     // solve had a different M^-1, every solve with the common M^-1 the same bits).  Rank 0's copy therefore replaces everybody's: the
@@ -923,6 +961,18 @@ struct nnsdp_solver {
     if (strm != st) RBCHK(rocblas_set_stream(roc->h, st));
   }
 
+  // hsum <- sum over ranks of the rank's own partial consensus sum (dual = 1: of nu - w): RCCL / the caller's collective, or the
+  // device-side transport (partial into this rank's mapped slot, publish, sum of all ranks' slots in rank order)
+  void exchange_h(int dual) {
+    const int ng = S.ng, NE = S.NE;
+    hipLaunchKernelGGL(k_gather_h, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
+                       nu.p + ng, w.p + ng, dual, ipc ? xbuf.p : hsum.p, ipc ? ipc_ctr.p : (const unsigned long long*)nullptr);
+    if (ipc) {
+      hipLaunchKernelGGL(nnsdp::k_ipc_publish, dim3(1), dim3(64), 0, st, ipa);
+      hipLaunchKernelGGL(nnsdp::k_ipc_reduce, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, ipa, hsum.p);
+    } else allreduce(hsum.p, NE);
+  }
+
   // enqueue one iteration on the stream; check=true also accumulates the residual sums
   void enqueue_iteration(bool check, bool warm, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     int ng = S.ng, NE = S.NE;
@@ -930,9 +980,7 @@ struct nnsdp_solver {
     enqueue_proj(warm);
     if (e1) HIPCHK(hipEventRecord(e1, st));
     if (sharded) {
-      hipLaunchKernelGGL(k_gather_h, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
-                         nu.p + ng, w.p + ng, 0, hsum.p);
-      allreduce(hsum.p, NE);                      // the overlap-consensus exchange: one all-reduce per iteration
+      exchange_h(0);                              // the overlap-consensus exchange: one all-reduce per iteration
       hipLaunchKernelGGL(k_finish_g, dim3(cdiv(NE, kThreads)), dim3(kThreads), 0, st, NE, hsum.p, D.z0.p, D.Dinv.p, d_sigma(), g.p);
     } else {
       const int nshort = cdiv(NE, kThreads);
@@ -943,9 +991,7 @@ struct nnsdp_solver {
                        D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
     if (check) {
       if (sharded) {
-        hipLaunchKernelGGL(k_gather_h, dim3(cdiv((long long)NE * kGatherLanes, kThreads)), dim3(kThreads), 0, st, NE, d_sptr_own.p, d_soff_own.p, d_isdiag.p,
-                           nu.p + ng, w.p + ng, 1, hsum.p);
-        allreduce(hsum.p, NE);
+        exchange_h(1);
       }
       const int nreg_cd = nb_dual - nlong;
       hipLaunchKernelGGL(k_check_dual, dim3(nb_dual), dim3(kThreads), 0, st, NE, ng, nreg_cd, nlong, d_long.p, D.csr_ptr.p,
@@ -1090,6 +1136,7 @@ struct nnsdp_solver {
     // rocSOLVER's convergence report of the library eigensolves, sticky since the solver was created.  Clique-sharded: only a block's
     // owner runs dsyevd, so the flag rides in the all-reduced control block (acc[7] >= 1024) and all ranks leave the loop together;
     // a rank-local exit would strand the others in the next iteration's all-reduce.
+    if (ipc && ipc_err.download()[0] != 0) throw HipError("clique-sharded exchange over hipIpc: a peer did not publish its partial sum in time (rank stopped or not co-scheduled)");
     if (!big_idx.empty()) {
       if (sharded) big_fail = big_fail || acc_host[7] >= 1024.0;
       else big_fail = big_fail || big_flag.download()[0] != 0;
@@ -2403,6 +2450,14 @@ int nnsdp_solver_set_comm_callback(nnsdp_solver* s, int32_t nranks, int32_t rank
   if (!s) throw std::invalid_argument("null solver");
   if (!fn) throw std::invalid_argument("null all-reduce callback");
   s->set_comm(nranks, rank, nullptr, fn, user);
+  API_END
+}
+
+int nnsdp_solver_set_comm_ipc(nnsdp_solver* s, int32_t nranks, int32_t rank, nnsdp_allreduce_fn fn, void* user) {
+  API_BEGIN
+  if (!s) throw std::invalid_argument("null solver");
+  if (!fn) throw std::invalid_argument("null all-reduce callback");
+  s->set_comm(nranks, rank, nullptr, fn, user, true);
   API_END
 }
 

@@ -2613,7 +2613,11 @@ __global__ __launch_bounds__(kThreads) void k_gather_g_b(const IterArgs* __restr
 // summed over ranks with one all-reduce, then k_finish_g
 __global__ __launch_bounds__(kThreads) void k_gather_h(int NE, const int* __restrict__ sptr, const long long* __restrict__ soff,
                                                         const unsigned char* __restrict__ isdiag, const double* __restrict__ nuk,
-                                                        const double* __restrict__ wk, int dual, double* __restrict__ h) {
+                                                        const double* __restrict__ wk, int dual, double* __restrict__ h,
+                                                        const unsigned long long* __restrict__ ipc_ctr) {
+  // (device-side transport: the partial sum goes into the slot of the NEXT exchange of this rank's mapped buffer; the exchange
+  // number lives on the device, so a replayed hipGraph picks the right slot whatever ran between two replays)
+  if (ipc_ctr) h += (size_t)((*ipc_ctr + 1) & 1) * NE;
   const int t = blockIdx.x * kThreads + threadIdx.x;
   const int e = t / kGatherLanes, sub = t % kGatherLanes;
   if (e >= NE) return;
@@ -2626,6 +2630,56 @@ __global__ __launch_bounds__(kThreads) void k_gather_h(int NE, const int* __rest
   if (sub != 0) return;
   if (!isdiag[e]) s *= kSqrt2;
   h[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Clique-sharded mode, device-side transport (round 4): the ranks are processes of one node whose exchange buffers are mapped into
+// each other's address space with hipIpc (one card, or peers over xGMI).  Every rank writes its partial consensus sum into slot
+// (exchange number & 1) of ITS buffer, publishes the exchange number behind a system-scope release, and then sums the slots of all
+// ranks in rank order - one-shot all-gather + local reduce, the same bits on every rank, no library kernel
+// in the iteration.  Two slots are enough: a rank can only reach exchange c + 2 after every peer has published c + 1, i.e. after it
+// has finished reading slot c & 1.  The wait is a bounded spin (a peer that never publishes sets the error word and the caller
+// throws at its next check instead of hanging the card).
+//   layout of a rank's buffer: [2][NE] doubles | flags[2] (unsigned long long) at double offset 2 NE
+// ---------------------------------------------------------------------------------------------
+struct IpcArgs {
+  double* peer[8];              // every rank's buffer in THIS process's address space (own buffer included), rank order
+  int nranks, rank, NE;
+  unsigned long long* ctr;      // this rank's exchange counter (device)
+  int* err;                     // set to 1 when a wait ran out
+  long long spin_limit;
+};
+__global__ void k_ipc_publish(IpcArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long c = *a.ctr + 1;
+  *a.ctr = c;
+  unsigned long long* flags = reinterpret_cast<unsigned long long*>(a.peer[a.rank] + 2 * (size_t)a.NE);
+  __threadfence_system();                                   // the slot's stores (previous kernel) are complete and visible
+  __hip_atomic_store(flags + (c & 1), c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(kThreads) void k_ipc_reduce(IpcArgs a, double* __restrict__ out) {
+  __shared__ int bad;
+  const unsigned long long c = *a.ctr;                      // (published by this rank earlier on the stream)
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < a.nranks && (int)threadIdx.x != a.rank) {      // one lane per peer: the waits (a fabric round trip each) overlap
+    const int r = threadIdx.x;
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(a.peer[r] + 2 * (size_t)a.NE) + (c & 1);
+    long long spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < c) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > a.spin_limit) { atomicExch(a.err, 1); bad = 1; break; }
+    }
+    __threadfence_system();
+  }
+  __syncthreads();
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= a.NE) return;
+  const size_t o = (size_t)(c & 1) * a.NE + e;
+  double s = 0.0;
+  for (int r = 0; r < a.nranks; ++r)      // (system-scope loads: a peer's lines may sit stale in this XCD's L2 from two exchanges ago)
+    s += __hip_atomic_load(a.peer[r] + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  out[e] = s;
 }
 
 __global__ __launch_bounds__(kThreads) void k_finish_g(int NE, const double* __restrict__ h, const double* __restrict__ z0,

@@ -98,6 +98,7 @@ SYMBOLS = [
     ("nnsdp_shard_plan", C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("nnsdp_solver_set_comm", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     ("nnsdp_solver_set_comm_callback", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]),
+    ("nnsdp_solver_set_comm_ipc", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]),
 ]
 
 _lib = None

@@ -444,6 +444,20 @@ class Solver:
         self._ar_cb = _lib.ALLREDUCE_FN(_cb)       # keep the trampoline alive as long as the handle
         _lib.check(self.lib.nnsdp_solver_set_comm_callback(self.h, int(nranks), int(rank), self._ar_cb, None))
 
+    def set_comm_ipc(self, nranks: int, rank: int, allreduce) -> None:
+        """clique-sharded mode with the device-side exchange over hipIpc-mapped peer buffers (ranks = processes of one node);
+        `allreduce` as in set_comm_callback: used for the set-up and the check iterations' control decisions only."""
+        def _cb(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                return 0
+            except Exception:      # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ar_cb = _lib.ALLREDUCE_FN(_cb)
+        _lib.check(self.lib.nnsdp_solver_set_comm_ipc(self.h, int(nranks), int(rank), self._ar_cb, None))
+
     def iterate_async(self, iters: int) -> None:
         _lib.check(self.lib.nnsdp_solver_iterate_async(self.h, int(iters)))
 

@@ -25,6 +25,37 @@ def main():
         calls[0] += 1
         dist.all_reduce(torch.from_numpy(a))      # in place on the library's host buffer
 
+    ipc = name.endswith(":ipc")              # the device-side transport (hipIpc-mapped peer buffers) instead of the host callback
+    if ipc:
+        name = name.split(":")[0]
+        import hashlib, time
+        q = helpers.acas_shaped_query() if name == "acas-shape" else helpers.product_query(helpers.load_problem(name, beta))
+        res = {"rank": rank}
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), proj_refine=0))
+        s.set_comm_ipc(world, rank, allreduce)
+        s.iterate(100)
+        dist.barrier()
+        t0 = time.perf_counter()
+        s.iterate(400)
+        res["us_per_iter_sharded_ipc"] = 1e6 * (time.perf_counter() - t0) / 400
+        res["graph_launches"] = s.info(0)
+        res["after_500"] = list(s.residuals())
+        res["mult501_digest"] = hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest()
+        s.close()
+        calls_setup = calls[0]
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
+        s.set_comm_ipc(world, rank, allreduce)
+        sol = s.run()
+        res["solve"] = dict(status=sol.termination_status, iters=int(sol.summary["iters"]), rho=float(sol.objective_value),
+                            admm=float(sol.summary["objective_admm"]), lambda_max=float(sol.summary["lambda_max"]), solve_s=float(sol.solve_time),
+                            gamma=np.concatenate([sol.values[k] for k in ("γin", "γout", "γac1", "γac2")]).tolist())
+        s.close()
+        res["host_allreduce_calls"] = calls[0] - calls_setup
+        dist.barrier()
+        dist.destroy_process_group()
+        with open(out, "w") as fh:
+            json.dump(res, fh)
+        return
     light = name.endswith(":light")          # BASELINE configs 4 / 5 (W40-D40, the ACAS shape): the plain-iteration leg and a capped solve
     name = name.split(":")[0]
     q = helpers.acas_shaped_query() if name == "acas-shape" else helpers.product_query(helpers.load_problem(name, beta))

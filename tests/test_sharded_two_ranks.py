@@ -134,3 +134,52 @@ def test_two_rank_sharded_baseline_configs_4_and_5(name, tmp_path):
     assert r0["blocks_owned"][0] == 0 and r0["blocks_owned"][1] == r1["blocks_owned"][0] and r1["blocks_owned"][1] == len(r0["blocks"])
     if name == "acas-shape":
         assert len(r0["blocks"]) == 5 and max(r0["blocks"]) == 151 and min(r0["blocks"]) > 80      # (106 + 4 x 151 less the coordinates the normalisation eliminates)
+
+
+@pytest.mark.parametrize("name", ["W40-D20", "W40-D40"])
+def test_two_rank_sharded_solve_over_the_device_side_transport(name, tmp_path):
+    """the sharded mode's per-iteration exchange as the library's own kernels over hipIpc-mapped peer buffers (nnsdp_solver_set_comm_ipc):
+    two processes on the card, no host on the data path (the iterations between checks replay a hipGraph that contains the exchange),
+    the same iterate as the serial run, identical bits on both ranks, a whole solve landing on the serial certificate; the cost of a
+    sharded iteration beside the serial one is recorded (gpurun_out/shard_ipc_*.json)."""
+    port = _free_port()
+    worker = os.path.join(helpers.ROOT, "tests", "shard_worker.py")
+    outs = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, name + ":ipc", "0", outs[r]]) for r in range(2)]
+    q = helpers.product_query(helpers.load_problem(name, 0))
+    try:
+        import time
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), proj_refine=0))
+        s.iterate(100)
+        t0 = time.perf_counter()
+        s.iterate(400)
+        us_serial = 1e6 * (time.perf_counter() - t0) / 400
+        ref500 = s.residuals()
+        s.close()
+        ref = na.runQuery(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), eps_rel=1e-5, max_iters=200000, max_time=200))
+        for p in procs:
+            assert p.wait(timeout=900) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    r0, r1 = (json.load(open(o)) for o in outs)
+    os.makedirs(os.path.join(helpers.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(helpers.ROOT, "gpurun_out", f"shard_ipc_{name}.json"), "w") as fh:
+        json.dump({"us_per_iteration": {"serial_one_process_beside_two_ranks": us_serial, "sharded_two_ranks_ipc": [r0["us_per_iter_sharded_ipc"], r1["us_per_iter_sharded_ipc"]]},
+                   "graph_launches": [r0["graph_launches"], r1["graph_launches"]], "host_allreduce_calls_in_the_solve": r0["host_allreduce_calls"],
+                   "solve": {k: v for k, v in r0["solve"].items() if k != "gamma"}, "serial_solve": [ref.termination_status, ref.summary["iters"], ref.solve_time]}, fh, indent=1)
+    print("us / iteration: serial", round(us_serial, 1), "sharded over two ranks on one card, hipIpc transport", [round(r["us_per_iter_sharded_ipc"], 1) for r in (r0, r1)])
+    rtol = 1e-5 if name == "W40-D40" else 1e-7
+    for r in (r0, r1):
+        assert np.allclose(r["after_500"], ref500, rtol=rtol, atol=1e-12), (r["after_500"], ref500)
+    assert r0["after_500"] == r1["after_500"] and r0["mult501_digest"] == r1["mult501_digest"]
+    assert r0["graph_launches"] > 0 and r1["graph_launches"] > 0            # the exchange ran inside replayed graphs
+    a, b = r0["solve"], r1["solve"]
+    assert a["status"] == b["status"] == ref.termination_status == "OPTIMAL"
+    assert a["iters"] == b["iters"]
+    assert np.array_equal(np.array(a["gamma"]), np.array(b["gamma"]))
+    assert abs(a["rho"] - ref.objective_value) <= 1e-3 * abs(ref.objective_value)
+    assert a["lambda_max"] <= 1e-6 and min(a["gamma"]) >= 0.0
+    assert r0["host_allreduce_calls"] < a["iters"] // 10                    # the host collective only at set-up and check iterations
