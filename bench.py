@@ -136,17 +136,45 @@ def main():
     ap.add_argument("--cert-seconds", type=float, default=30.0, help="time cap of the time-to-certificate solve (0 = skip)")
     ap.add_argument("--wide-burn-in", type=int, default=8000,
                     help="iterations before the timed window of the wide-block leg (ACAS-Xu shaped network, the reference's 151-wide cliques; 0 = skip)")
+    ap.add_argument("--no-torch", action="store_true",
+                    help="N = 1 only: do not import torch (device synchronisation through the HIP runtime directly); a diagnostic that separated "
+                         "torch from the library when rocprofv3 --pmc died at start-up (the cause was neither: the load order, see below)")
     args = ap.parse_args()
 
-    import torch
+    if os.environ.get("NNSDP_BENCH_WATCHDOG"):      # (diagnostic) Python stack of every thread after that many seconds, then exit: where does a run hang?
+        import faulthandler
+        faulthandler.enable()
+        faulthandler.dump_traceback_later(float(os.environ["NNSDP_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if os.environ.get("NNSDP_BENCH_ONE_DEVICE"):    # rehearsal of the N > 1 control flow on a one-GPU box (all ranks on device 0)
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if args.no_torch:
+        if world > 1:
+            raise SystemExit("--no-torch is for N = 1 (the launcher and the control plane of N > 1 are torch.distributed)")
+        # the library first, the HIP runtime calls after it: under rocprofv3 --pmc a code object registered AFTER the runtime is up
+        # hangs or kills the tool on this pool (found with NNSDP_BENCH_WATCHDOG: the stack ends in ctypes.CDLL of the library)
+        from nnsdp_amd import _lib as _nl
+        _nl.load()
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        ndev = ctypes.c_int(0)
+        if hip.hipGetDeviceCount(ctypes.byref(ndev)) != 0 or ndev.value < 1:
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        hip.hipSetDevice(local_rank)
+
+        def dev_sync():
+            if hip.hipDeviceSynchronize() != 0:
+                raise RuntimeError("hipDeviceSynchronize failed")
+    else:
+        import torch
+        from nnsdp_amd import _lib as _nl
+        _nl.load()              # (before the first call that brings the HIP runtime up: see above)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev_sync = torch.cuda.synchronize
     dist = None
     if world > 1:
         # control plane only (launch, barrier, max over ranks, the 128-byte RCCL id): gloo, so that the one RCCL
@@ -161,10 +189,10 @@ def main():
     opts = na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9, device=local_rank)
 
     def barrier():
-        torch.cuda.synchronize()
+        dev_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def all_max(v):
         if dist is None:
@@ -233,11 +261,11 @@ def main():
     # hipGraph replay rate of the same iteration (what nnsdp_solve itself uses): the graph is captured and instantiated by an untimed
     # call first, and at least 256 iterations are timed whatever --steps is (a 20-step window used to contain the capture)
     solver.iterate(64)                  # every rank runs these too (sharded mode: collective inside)
-    torch.cuda.synchronize()
+    dev_sync()
     g_steps = max(args.steps, 2048)
     tg0 = time.perf_counter()
     solver.iterate(g_steps)
-    torch.cuda.synchronize()
+    dev_sync()
     graph_ips = g_steps / (time.perf_counter() - tg0)
     # the same measurement deep in the solve: a solve to residuals 1e-6 takes 59 000 iterations in this decomposition, and from about
     # 10 000 on the projection kernel's refinement stage carries nearly every block (the sweeps are the early-phase path)
@@ -245,16 +273,16 @@ def main():
     if args.late_burn_in > 0 and world == 1:
         solver.advance(args.late_burn_in)
         solver.iterate(args.warmup, time_eig=True)
-        torch.cuda.synchronize()
+        dev_sync()
         tl0 = time.perf_counter()
         ms_l = solver.iterate(args.steps, time_eig=True)
-        torch.cuda.synchronize()
+        dev_sync()
         dtl = time.perf_counter() - tl0
         solver.iterate(64)
-        torch.cuda.synchronize()
+        dev_sync()
         tl1 = time.perf_counter()
         solver.iterate(g_steps)
-        torch.cuda.synchronize()
+        dev_sync()
         late = {"after_iters": args.burn_in + args.late_burn_in, "iters_per_s": args.steps / dtl, "kernel_avg_us": 1e3 * ms_l / args.steps,
                 "graph_replay_iters_per_s": g_steps / (time.perf_counter() - tl1)}
     solver.close()
@@ -355,10 +383,10 @@ def main():
         # comparison with BENCH_r01.json: the first iterations of a solve are not the regime it spends its time in
         s0 = na.Solver(q, opts)
         s0.iterate(5, time_eig=True)
-        torch.cuda.synchronize()
+        dev_sync()
         t1 = time.perf_counter()
         ms0 = s0.iterate(20, time_eig=True)
-        torch.cuda.synchronize()
+        dev_sync()
         dt0 = time.perf_counter() - t1
         s0.close()
         out["round1_window"] = {"warmup": 5, "steps": 20, "burn_in_iters": 0, "iters_per_s": 20 / dt0, "kernel_avg_us": 1e3 * ms0 / 20,
@@ -390,10 +418,10 @@ def main():
         rates = {}
         for name, fn in (("fused", sb.iterate), ("streams", sb.iterate_streams)):
             fn(max(args.warmup, 16))
-            torch.cuda.synchronize()
+            dev_sync()
             tb = time.perf_counter()
             fn(args.steps)
-            torch.cuda.synchronize()
+            dev_sync()
             rates[name] = args.batch * args.steps / (time.perf_counter() - tb)
         sb.close()
         agg = rates["fused"]
@@ -417,10 +445,10 @@ def main():
         sw = na.Solver(qw, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9))
         sw.advance(args.wide_burn_in)
         sw.iterate(16, time_eig=True)
-        torch.cuda.synchronize()
+        dev_sync()
         t1 = time.perf_counter()
         msw = sw.iterate(200, time_eig=True)
-        torch.cuda.synchronize()
+        dev_sync()
         dtw = time.perf_counter() - t1
         smw = sw.finish().summary
         sw.close()

@@ -3,19 +3,32 @@
 # aggregated into gpurun_out/profiles_new/ (copy into profiles/ afterwards).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 export TMPDIR=/tmp
+# the runtime's graph packet capture pre-builds AQL packets with device-resident kernel arguments, and rocprofv3's queue interception
+# dereferences them on the host (SIGSEGV inside the tool: round 2 for the batched run, round 4 for every --pmc pass once the check
+# iteration became a graph of its own); the same graphs replay through the ordinary dispatch path with the feature off
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 cd /tmp
 BURN=2000; WARM=50; STEPS=200; LATE=18000
 ARGS="--steps $STEPS --warmup $WARM --burn-in $BURN --late-burn-in $LATE --batch 0 --no-cpu-baseline --cert-seconds 0 --wide-burn-in 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
+# Counter passes (round 4): rocprofv3 --pmc segfaults in one of its own threads when bench.py itself is the profiled process (5 of 5
+# runs with these arguments, torch or not, set-up thread or not, graph packet capture on or off: tools/pmc_probe.sh; the first cause
+# found - a code object registered after the HIP runtime is up hangs the tool - is fixed in bench.py and was not the last one), and a
+# graph-replayed solve loop kills it too.  It collects fine on the SAME handle sequence issued without bench.py's process around it
+# (tools/pmc_window.py: burn-in, warm-up + window, late burn-in, late window; eager launches - a kernel's counters do not depend on
+# how it was launched), so that is what the four passes profile.
+export NNSDP_NO_GRAPH=1
+PW="$R/tools/pmc_window.py $BURN $WARM $STEPS $LATE"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $PW > /dev/null 2> $OUT/pmc_$C.err || echo "pmc pass $C failed"
 done
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_LDS -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_LDS.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_SQ.err || true
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_LDS -- python3 $PW > /dev/null 2> $OUT/pmc_LDS.err || echo 'pmc pass LDS failed'
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 $PW > /dev/null 2> $OUT/pmc_SQ.err || echo 'pmc pass SQ failed'
+unset NNSDP_NO_GRAPH
 cd $R
 python3 - "$OUT" "$TAG" $BURN $WARM $STEPS $LATE <<'PY'
 import csv, collections, glob, json, sys, shutil
@@ -41,9 +54,9 @@ for p in glob.glob(out + "/stats/*/*kernel_trace.csv"):
         d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(f) if "k_proj_jacobi" in r["Kernel_Name"])
     dur = [(e - s) / 1e3 for s, e in d]
     win = dur[burn + warm: burn + warm + steps]
-    # bench.py after the first window: 1 check iteration (residuals), 64 + max(steps, 256) graph-replay iterations, the late burn-in,
+    # bench.py after the first window: 1 check iteration (residuals), 64 + max(steps, 2048) graph-replay iterations, the late burn-in,
     # the warm-up, then the late window
-    l0 = burn + warm + steps + 1 + 64 + max(steps, 256) + late + warm
+    l0 = burn + warm + steps + 1 + 64 + max(steps, 2048) + late + warm
     lwin = dur[l0: l0 + steps]
     json.dump({"kernel": "k_proj_jacobi", "launches": len(dur), "avg_us_all_launches": sum(dur) / len(dur),
                "timed_window": {"first_launch": burn + warm, "launches": len(win), "avg_us": sum(win) / max(len(win), 1)},
@@ -64,9 +77,7 @@ PY
 # library's capture is at fault (one stream, no events, no cross-stream work inside it); turning the runtime feature off for the
 # profiled run lets the same graphs replay through the ordinary dispatch path.
 cd /tmp
-export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bstats -- python3 $R/tools/batch_bench.py 13 W40-D20 400 > $OUT/${TAG}_batched13_W40-D20.log 2> $OUT/bstats.err
-unset DEBUG_CLR_GRAPH_PACKET_CAPTURE
 cd $R
 for f in $OUT/bstats/*/*kernel_stats.csv; do cp $f $OUT/${TAG}_batched13_W40-D20_kernel_stats.csv; done
 rm -rf $OUT/stats $OUT/pmc_* $OUT/bstats   # raw traces are large; only the aggregates travel back
