@@ -199,7 +199,8 @@ int nnsdp_solver_apply_minv(nnsdp_solver* s, const double* q, double* out, int32
  * test compares it bit for bit between ranks. */
 int nnsdp_solver_raw_multipliers(nnsdp_solver* s, double* out);
 /* diagnostic: what = 0 hipGraph launches so far, 1 whether an ncclAllReduce could be captured into a hipGraph (sharded mode over RCCL),
- * 2 clique-sharded mode on, 3 iterations done, 4 PSD blocks, 5 largest block */
+ * 2 clique-sharded mode on, 3 iterations done, 4 PSD blocks, 5 largest block, 6 the hipIpc transport (0 off, 1 on with ordinary device
+ * memory behind the exchange buffers, 2 on with fine-grained device memory - the default) */
 int nnsdp_solver_info(nnsdp_solver* s, int32_t what, double* out);
 /* iterate until converged / limits; fills r like nnsdp_solve */
 int nnsdp_solver_run(nnsdp_solver* s, nnsdp_result* r);

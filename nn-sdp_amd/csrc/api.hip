@@ -62,6 +62,16 @@ struct DBuf {
     n = count;
     if (count) HIPCHK(hipMalloc(&p, count * sizeof(T)));
   }
+  // fine-grained device memory: coherent across devices WHILE kernels run (the hipIpc exchange buffers: a peer's kernel polls a flag
+  // and reads data another device's kernel is publishing; coarse-grained memory only promises that at kernel boundaries)
+  bool alloc_finegrained(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    void* q = nullptr;
+    if (hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); n = 0; return false; }
+    p = static_cast<T*>(q);
+    return true;
+  }
   void upload(const std::vector<T>& h) {
     alloc(h.size());
     if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -399,6 +409,7 @@ struct nnsdp_solver {
   DBuf<int> ipc_err;
   nnsdp::IpcArgs ipa{};
   std::vector<void*> ipc_opened;
+  bool ipc_fine = false;               // exchange buffers in fine-grained device memory
 
   ~nnsdp_solver() {
     if (comm) (void)Rccl::get().CommDestroy(comm);
@@ -793,10 +804,17 @@ struct nnsdp_solver {
     if (use_ipc) {
       // every rank maps every other rank's exchange buffer: the 64-byte hipIpc handles travel once through the caller's host
       // all-reduce (one byte per double: a sum of zeros and one value is exact whatever the bit pattern)
-      xbuf.alloc(2 * (size_t)S.NE + 4); xbuf.zero();
-      ipc_ctr.alloc(1); ipc_ctr.zero(); ipc_err.alloc(1); ipc_err.zero();
+      static const bool coarse = [] { const char* e = std::getenv("NNSDP_IPC_COARSE"); return e && std::atoi(e) != 0; }();   // diagnostic
       hipIpcMemHandle_t mine;
-      HIPCHK(hipIpcGetMemHandle(&mine, xbuf.p));
+      bool fine = !coarse && xbuf.alloc_finegrained(2 * (size_t)S.NE + 4);
+      if (fine && hipIpcGetMemHandle(&mine, xbuf.p) != hipSuccess) { (void)hipGetLastError(); fine = false; }
+      if (!fine) {                     // (a runtime that cannot share a fine-grained allocation: ordinary device memory, coherent by the
+        xbuf.alloc(2 * (size_t)S.NE + 4);   //  system-scope release / acquire pair around the flag on one device)
+        HIPCHK(hipIpcGetMemHandle(&mine, xbuf.p));
+      }
+      ipc_fine = fine;
+      xbuf.zero();
+      ipc_ctr.alloc(1); ipc_ctr.zero(); ipc_err.alloc(1); ipc_err.zero();
       static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpc handle size");
       std::vector<double> all((size_t)nr * 64, 0.0);
       const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mine);
@@ -1965,6 +1983,7 @@ int nnsdp_solver_info(nnsdp_solver* s, int32_t what, double* out) {
     case 3: *out = (double)s->iters_done; break;
     case 4: *out = (double)s->ncl; break;
     case 5: *out = (double)s->nmax; break;
+    case 6: *out = s->ipc ? (s->ipc_fine ? 2.0 : 1.0) : 0.0; break;
     default: throw std::invalid_argument("unknown info item");
   }
   API_END

@@ -482,7 +482,7 @@ class Solver:
         return out
 
     def info(self, what: int) -> float:
-        """nnsdp_solver_info: 0 hipGraph launches, 1 RCCL all-reduce capturable into a hipGraph, 2 sharded, 3 iterations, 4 blocks, 5 largest block"""
+        """nnsdp_solver_info: 0 hipGraph launches, 1 RCCL all-reduce capturable into a hipGraph, 2 sharded, 3 iterations, 4 blocks, 5 largest block, 6 hipIpc transport (2 = fine-grained exchange buffers)"""
         v = C.c_double()
         _lib.check(self.lib.nnsdp_solver_info(self.h, int(what), C.byref(v)))
         return v.value

@@ -39,6 +39,7 @@ def main():
         s.iterate(400)
         res["us_per_iter_sharded_ipc"] = 1e6 * (time.perf_counter() - t0) / 400
         res["graph_launches"] = s.info(0)
+        res["ipc_transport"] = s.info(6)
         res["after_500"] = list(s.residuals())
         res["mult501_digest"] = hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest()
         s.close()

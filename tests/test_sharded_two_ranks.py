@@ -176,6 +176,7 @@ def test_two_rank_sharded_solve_over_the_device_side_transport(name, tmp_path):
         assert np.allclose(r["after_500"], ref500, rtol=rtol, atol=1e-12), (r["after_500"], ref500)
     assert r0["after_500"] == r1["after_500"] and r0["mult501_digest"] == r1["mult501_digest"]
     assert r0["graph_launches"] > 0 and r1["graph_launches"] > 0            # the exchange ran inside replayed graphs
+    assert r0["ipc_transport"] == 2.0 and r1["ipc_transport"] == 2.0        # exchange buffers in fine-grained memory (coherent across devices while kernels run)
     a, b = r0["solve"], r1["solve"]
     assert a["status"] == b["status"] == ref.termination_status == "OPTIMAL"
     assert a["iters"] == b["iters"]

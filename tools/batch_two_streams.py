@@ -26,6 +26,8 @@ def rate(groups):
     for b in bs: b.close()
     return sum(groups) * timed / dt, 1e6 * dt / timed
 
-for groups in ([B], [B - B // 2, B // 2], [B - 2 * (B // 3), B // 3, B // 3]):
+def split(n, g):
+    return [n // g + (1 if i < n % g else 0) for i in range(g)]
+for groups in [split(B, g) for g in (1, 2, 3, 4, 5, 6, 13)] + [[7, 6], [B]]:
     r, us = rate(groups)
     print(f"groups {groups}: {r:.0f} aggregate it/s ({us:.1f} us per lockstep iteration of the slowest group)", flush=True)
