@@ -793,6 +793,9 @@ struct RefinePipe {
          *psum = nullptr;
   int *vrec = nullptr, *pmode = nullptr;
   bool ready = false;
+  RefinePipe() = default;
+  RefinePipe(const RefinePipe&) = delete;            // (owns device memory)
+  RefinePipe& operator=(const RefinePipe&) = delete;
   ~RefinePipe() { release(); }
   void release() {
     void* ps[] = {wgmap, T, E, U, Vt, Et, drec, dpart, rdg, lpart, frop, psum, vrec, pmode};
