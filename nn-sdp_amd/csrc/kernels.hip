@@ -308,28 +308,53 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
   double fro2 = 0.0;
   const bool warm = a.warm != 0;
   if constexpr (PP) {
-    // every global load of the block (matrix, read ONCE and coalesced, and the warm basis) is issued before the
-    // first LDS store; the matrix is symmetrised in LDS afterwards
-    constexpr int JT = 6, IT = 2;   // 96 columns / 16 waves, 96 rows / 64 lanes
+    // every global load of the block (matrix, read ONCE, and the warm basis) is issued before the first LDS store; the matrix is
+    // symmetrised in LDS afterwards.  The block is n^2 contiguous doubles: thread t takes the 16-byte pieces t, t + 1024, ... of that
+    // LINEAR range (8 + 8 wave instructions per thread instead of 12 + 12 guarded 8-byte ones - a CU issues one vector-memory wave
+    // instruction per ~13 cycles whatever its width, tools/load_issue_probe.hip - every load unconditional from a clamped address:
+    // no exec-mask branch around it) and finds (row, column) of its two elements afterwards.
+    constexpr int MR = 5;            // ceil(96 * 96 / 2 / 1024) pieces per thread
     const int ln = tid & 63, wvi = tid >> 6;
     const double* vgk = a.Vg + a.coff[k];
-    double ta[JT][IT], tv[JT][IT];
+    const int n2 = n * n, npc = (n2 + 1) >> 1;             // elements, pieces (the last one of an odd block is moved back by one)
+    double2 ta[MR], tv[MR];
 #pragma unroll
-    for (int jj = 0; jj < JT; ++jj)
-#pragma unroll
-      for (int ii = 0; ii < IT; ++ii) {
-        const int j = wvi + 16 * jj, i = ln + 64 * ii;
-        const bool in = i < n && j < n;
-        ta[jj][ii] = in ? nuk[(size_t)j * n + i] : 0.0;
-        tv[jj][ii] = (warm && in) ? vgk[(size_t)j * n + i] : (i == j ? 1.0 : 0.0);
+    for (int m = 0; m < MR; ++m) {
+      const int e = min(2 * (tid + NT * m), n2 - 2);
+      if (NT * m < npc) {
+        ta[m] = *reinterpret_cast<const double2*>(nuk + e);
+        if (warm) tv[m] = *reinterpret_cast<const double2*>(vgk + e);
       }
+    }
+    // padding first (rows / columns n .. npg - 1: zero in A, identity in V), disjoint from what the pieces write
+    const float rn = 1.0f / (float)n, rg = 1.0f / (float)npg;
+    const int pad = npg - n;
+    for (int q = tid; q < pad * npg; q += NT) {            // rows n .. npg - 1, every column
+      const int r = (int)(((float)q + 0.5f) * rg), j = q - r * npg, i = n + r;
+      A[i * lda + j] = 0.0; V[i + j * ldv] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int q = tid; q < pad * n; q += NT) {              // columns n .. npg - 1, rows below n
+      const int r = (int)(((float)q + 0.5f) * rn), i = q - r * n, j = n + r;
+      A[i * lda + j] = 0.0; V[i + j * ldv] = 0.0;
+    }
 #pragma unroll
-    for (int jj = 0; jj < JT; ++jj)
-#pragma unroll
-      for (int ii = 0; ii < IT; ++ii) {
-        const int j = wvi + 16 * jj, i = ln + 64 * ii;
-        if (i < npg && j < npg) { A[i * lda + j] = ta[jj][ii]; V[i + j * ldv] = tv[jj][ii]; }
+    for (int m = 0; m < MR; ++m) {
+      const int pc = tid + NT * m;
+      if (pc < npc) {
+        int e = 2 * pc;
+        double a0 = ta[m].x, a1 = ta[m].y, v0 = warm ? tv[m].x : 0.0, v1 = warm ? tv[m].y : 0.0;
+        const bool moved = e > n2 - 2;                     // (odd n^2: the last piece was read from n2 - 2 and holds (n2 - 2, n2 - 1))
+        if (moved) { a0 = a1; v0 = v1; }
+        int j = (int)(((float)e + 0.5f) * rn), i = e - j * n;          // nu_k[j n + i]: column j, row i (e < 9216: the float quotient is exact)
+        if (!warm) v0 = (i == j) ? 1.0 : 0.0;
+        A[i * lda + j] = a0; V[i + j * ldv] = v0;
+        if (!moved) {
+          ++i; if (i == n) { i = 0; ++j; }
+          if (!warm) v1 = (i == j) ? 1.0 : 0.0;
+          A[i * lda + j] = a1; V[i + j * ldv] = v1;
+        }
       }
+    }
     RST(12)
     __syncthreads();
     RST(13)
