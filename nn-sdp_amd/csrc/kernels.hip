@@ -117,7 +117,20 @@ struct ProjArgs {
   double tol;             // stop after a sweep that started with off(A)/|A|_F <= tol (quadratic convergence: it ends near tol^2)
   const int* pmode;       // per block, may be null: != 0 = the tile-parallel pipeline launched in front (refine_pipe.hpp) has already
                           // projected this block in this iteration; the workgroup returns at once
+  // two workgroups per block for the warm-start congruence (ping-pong variant, warm launches of one SDP; launch_proj): the grid is
+  // 2 x nblk - workgroups [0, nblk) are HELPERS (they never wait: dispatched first, they always finish), [nblk, 2 nblk) LEADERS.  Both
+  // load the block; each computes the tile columns of T = A V and of B = V'T it owns (same instruction sequence per tile as the
+  // one-workgroup form: identical bits); the helper leaves its tiles of B in `sB` behind a release of `sack[k]` and exits, the leader
+  // takes them after its own and goes on alone.  sack / sseen count the exchanges per block (device-resident: replayed graphs need no
+  // per-launch argument); a wait that runs out sets *serr (the solve ends with NUMERICAL_ERROR at its next check).
+  int split, nblk;
+  double* sB;             // nblk x kSplitTileDoubles
+  unsigned* sack;         // per block: exchanges completed by the helper
+  unsigned* sseen;        // per block: exchanges consumed by the leader
+  int* serr;
+  long long spin_limit;
 };
+static constexpr int kSplitTileDoubles = 96 * 96;      // tile-ordered storage of one block's B (6 x 6 tiles of 256 doubles)
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
 __device__ __forceinline__ int sym_at(int i, int j, int lda) { return i >= j ? i * lda + j : j * lda + i; }
@@ -257,7 +270,7 @@ static constexpr int kSysHead = 16 + 66;   // red[16], sel[npg + 2 <= 130 ints] 
 // ALG = 2: register-resident systolic sweeps (below).  SPW = pair slots (2 matrix rows each) per wave, RPW = eigenvector
 // rows per wave; NT/64 * SPW >= ceil(n/2) and NT/64 * RPW >= n + 1 for every block of the launch.
 template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
-__device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
+__device__ __forceinline__ void proj_body(const ProjArgs& a, const int k, const int role = 0) {      // role: 0 alone, 1 leader, 2 helper (ProjArgs::split)
   constexpr bool BLOCK = ALG == 1;
   constexpr bool SYS = ALG == 2;
   constexpr bool PP = ALG == 3;
@@ -405,22 +418,43 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 #endif
   const int nv = V_LDS ? np : n;  // rows/cols of V that exist
   // A <- V' A V on the matrix cores (V in LDS); a lambda because the refinement stage's fall-back re-runs it
-  auto congruence = [&]() {
+  auto congruence = [&](const int part) {
     // A <- V' A V with v_mfma_f64_16x16x4_f64: T = A V (all 16x16 tiles), then A' = V' T (lower tiles; the
     // Jacobi sweeps read the lower triangle only).  Operand maps (verified on gfx950): lane l holds
     // A[l&15][l>>4], B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
+    // part: 0 = the whole product; 1 / 2 = the leader's / the helper's tile columns of a split block (helper: columns 1 .. hc,
+    // leader: 0 and hc + 1 .. nt - 1 - the lower triangle's long columns are shared out: 9 + 12 tiles of 21 at nt = 6)
     constexpr int NW = NT / 64;
     constexpr int MAXT = (NT == 512) ? 5 : 3;  // ceil(36 tiles / 16 waves), ceil(36 / 8), ceil(9 / 4)
     const int nt = npg >> 4, ks = (np + 3) >> 2;   // rows / columns past np are zero (identity in V): the K loop stops at np
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lc = lane >> 4;
+    const int hc = (nt + 1) >> 1;
+    const int ncol = part == 0 ? nt : part == 2 ? hc : nt - hc;
+    auto colof = [&](int c) { return part == 0 ? c : part == 2 ? c + 1 : (c == 0 ? 0 : hc + c); };
+    // lower tile number t of this part -> (ti, tj); false past the end
+    auto lower_tile = [&](int t, int& ti, int& tj) {
+      if (part == 0) {
+        if (t >= nt * (nt + 1) / 2) return false;
+        ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tj = t - ti * (ti + 1) / 2;
+        return true;
+      }
+      for (int c = 0; c < ncol; ++c) {
+        const int cj = colof(c), cnt = nt - cj;
+        if (t < cnt) { tj = cj; ti = cj + t; return true; }
+        t -= cnt;
+      }
+      return false;
+    };
     d4_t acc[MAXT];
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
       int t = wv + m * NW;
       d4_t c = {0.0, 0.0, 0.0, 0.0};
-      if (t < nt * nt) {
-        int ti = t / nt, tj = t - ti * nt;
+      if (t < nt * ncol) {
+        int ti = t / ncol, tj = colof(t - ti * ncol);
         const double* ap = A + (16 * ti + lr) * lda + lc;
         const double* bp = V + lc + (size_t)(16 * tj + lr) * ldv;
         for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk], c, 0, 0, 0);
@@ -431,39 +465,74 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
       int t = wv + m * NW;
-      if (t < nt * nt) {
-        int ti = t / nt, tj = t - ti * nt;
+      if (t < nt * ncol) {
+        int ti = t / ncol, tj = colof(t - ti * ncol);
 #pragma unroll
         for (int r = 0; r < 4; ++r) A[(16 * ti + lc + 4 * r) * lda + 16 * tj + lr] = acc[m][r];
       }
     }
     __syncthreads();
-    const int ntl = nt * (nt + 1) / 2;
+    int tis[MAXT], tjs[MAXT];
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
       int t = wv + m * NW;
       d4_t c = {0.0, 0.0, 0.0, 0.0};
-      if (t < ntl) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        int tj = t - ti * (ti + 1) / 2;
+      tis[m] = -1; tjs[m] = 0;
+      int ti, tj;
+      if (lower_tile(t, ti, tj)) {
+        tis[m] = ti; tjs[m] = tj;
         const double* ap = V + lc + (size_t)(16 * ti + lr) * ldv;   // V'[i][k] = V[k][i]
         const double* bp = A + lc * lda + 16 * tj + lr;             // T[k][j]
         for (int kk = 0; kk < ks; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk * lda], c, 0, 0, 0);
       }
       acc[m] = c;
     }
+    if (part == 2) {
+      // helper: its tiles of B go to the exchange buffer in tile order (tile (ti, tj) at (ti nt + tj) x 256, element (lc + 4 r, lr) at
+      // 64 r + lane), then one release of the block's exchange count; nothing else of this workgroup is needed
+      double* const out = a.sB + (size_t)k * kSplitTileDoubles;
+#pragma unroll
+      for (int m = 0; m < MAXT; ++m)
+        if (tis[m] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(size_t)(tis[m] * nt + tjs[m]) * 256 + 64 * r + lane] = acc[m][r];
+        }
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.sack + k, a.sack[k] + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
-      int t = wv + m * NW;
-      if (t < ntl) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        int tj = t - ti * (ti + 1) / 2;
+      if (tis[m] >= 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[(16 * ti + lc + 4 * r) * lda + 16 * tj + lr] = acc[m][r];
+        for (int r = 0; r < 4; ++r) A[(16 * tis[m] + lc + 4 * r) * lda + 16 * tjs[m] + lr] = acc[m][r];
       }
+    }
+    if (part == 1) {
+      // leader: the helper's tiles (columns 1 .. hc), one per wave and round, behind an acquire of the exchange count
+      const unsigned want = a.sseen[k] + 1u;
+      if (tid == 0) {
+        long long spins = 0;
+        while (__hip_atomic_load(a.sack + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > a.spin_limit) { atomicExch(a.serr, 1); break; }
+        }
+      }
+      __syncthreads();
+      const double* const in = a.sB + (size_t)k * kSplitTileDoubles;
+      int nth = 0;
+      for (int c = 1; c <= hc; ++c) nth += nt - c;
+      for (int t = wv; t < nth; t += NW) {
+        int tt = t, ti = 0, tj = 0;
+        for (int c = 1; c <= hc; ++c) { const int cnt = nt - c; if (tt < cnt) { tj = c; ti = c + tt; break; } tt -= cnt; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          A[(16 * ti + lc + 4 * r) * lda + 16 * tj + lr] = __hip_atomic_load(in + (size_t)(ti * nt + tj) * 256 + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (tid == 0) a.sseen[k] = want;
     }
     __syncthreads();
     if (BLOCK) {   // block mode reads both triangles: mirror the lower one
@@ -561,7 +630,8 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
     __syncthreads();
   };
   if (warm && V_LDS) {
-    congruence();
+    congruence(PP ? role : 0);
+    if (PP && role == 2) return;
   } else if (warm && PK) {
     pk_congruence();
   } else if (warm) {
@@ -894,7 +964,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
             A[i * lda + j] = v;
           }
         __syncthreads();
-        congruence();
+        congruence(0);
       };
       // predicted error of the projection after one step: second-order residual coupling |[E, K]| / 2 <= |E| |K| (measured: 0.3 |E| |K|
       // at the median, 1.3 at the worst), the couplings left alone, and the third-order defect of exp(K) ~ I + K + K^2 / 2, which hits
@@ -2397,7 +2467,17 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k) {
 }
 
 template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
-__global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) { proj_body<V_LDS, NT, ALG, SPW, RPW>(a, blockIdx.x); }
+__global__ __launch_bounds__(NT) void k_proj_jacobi(ProjArgs a) {
+  int k = blockIdx.x, role = 0;
+  if (ALG == 3 && a.split) {
+    // helpers first (they never wait), leaders from the next multiple of 8: workgroup ids go round robin over the 8 XCDs, so a block's
+    // two workgroups share an XCD - and its L2, through which the helper's tiles travel
+    const int nb8 = (a.nblk + 7) & ~7;
+    if (k < nb8) { if (k >= a.nblk) return; role = 2; }
+    else { k -= nb8; role = 1; }
+  }
+  proj_body<V_LDS, NT, ALG, SPW, RPW>(a, k, role);
+}
 // one launch for the blocks of SEVERAL independent SDPs: map[blockIdx.x] = (SDP, block of that SDP)
 template <bool V_LDS, int NT, int ALG = 0, int SPW = 1, int RPW = 1>
 __global__ __launch_bounds__(NT) void k_proj_jacobi_b(const ProjArgs* __restrict__ args, const int2* __restrict__ map) {
@@ -2427,9 +2507,13 @@ inline bool proj_pp_ok(int nmax) { return nmax > kSmallBlock && nmax <= 96; }   
 inline void launch_proj(const ProjArgs& a, int nblocks, int nmax, bool v_lds, size_t lds, hipStream_t st, int alg = kProjRoundRobin) {
   if (alg == kProjPacked) { hipLaunchKernelGGL((k_proj_jacobi<false, 1024, 4>), dim3(nblocks), dim3(1024), lds, st, a); return; }
   if (alg == kProjPingPong && proj_pp_ok(nmax) && v_lds) {
-    if (nmax <= 74) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 5>), dim3(nblocks), dim3(1024), lds, st, a);
-    else if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(nblocks), dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 7>), dim3(nblocks), dim3(1024), lds, st, a);
+    const bool split = a.split != 0 && a.warm != 0 && a.nblk == nblocks;
+    ProjArgs b = a;
+    b.split = split ? 1 : 0;
+    const int grid = split ? ((nblocks + 7) & ~7) + nblocks : nblocks;
+    if (nmax <= 74) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 5>), dim3(grid), dim3(1024), lds, st, b);
+    else if (nmax <= 90) hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 6>), dim3(grid), dim3(1024), lds, st, b);
+    else hipLaunchKernelGGL((k_proj_jacobi<true, 1024, 3, 1, 7>), dim3(grid), dim3(1024), lds, st, b);
     return;
   }
   if (alg == kProjSystolic && proj_sys_ok(nmax)) {

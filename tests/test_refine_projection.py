@@ -355,3 +355,28 @@ def test_solver_with_the_pipeline_agrees(pipe, monkeypatch):
     assert abs(on.summary["iters"] - off.summary["iters"]) <= 0.25 * off.summary["iters"]
     assert on.summary["lambda_max"] <= 1e-7
     print("solve seconds with / without the pipeline:", on.solve_time, off.solve_time, "block visits", on.summary["refine_blocks"])
+
+
+@pytest.mark.parametrize("n", [57, 85, 96])
+def test_two_workgroups_per_block_give_identical_bits(n, monkeypatch):
+    """ProjArgs::split (off by default: measured slower, DESIGN.md section 4): the warm-start congruence shared between two workgroups
+    per block - helper's tiles through L2 behind a release / acquire pair - must reproduce the one-workgroup launch bit for bit
+    (same instruction sequence per tile), on the step path, the converged path and the sweeps"""
+    rng = np.random.default_rng(n)
+    def sym():
+        spec = np.concatenate([np.linspace(0.2, 2.0, n - n // 3), -np.linspace(0.1, 1.5, n // 3)])
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        return (Q * spec) @ Q.T, Q
+    base = [sym() for _ in range(7)]
+    for eta, tol, refine in ((1e-6, 3e-7, True), (0.0, 1e-7, True), (3e-2, 1e-6, True), (1e-6, 3e-7, False)):
+        mats = []
+        for A, _ in base:
+            D = rng.standard_normal(A.shape); D = 0.5 * (D + D.T)
+            mats.append(A + eta * np.linalg.norm(A) / np.linalg.norm(D) * D)
+        out = []
+        for split in ("0", "1"):
+            monkeypatch.setenv("NNSDP_SPLIT_WARM", split)
+            out.append(na.project_psd_warm(mats, [Q for _, Q in base], tol, refine=refine))
+        for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+            assert np.array_equal(a, b)
+        assert list(out[0][2]) == list(out[1][2])
