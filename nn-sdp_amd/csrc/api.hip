@@ -412,7 +412,7 @@ struct nnsdp_solver {
   bool ipc_fine = false;               // exchange buffers in fine-grained device memory
   // two workgroups per block for the warm-start congruence (ProjArgs::split): ping-pong variant, one SDP, no compacted block list
   DBuf<double> split_B;
-  DBuf<unsigned> split_ack, split_seen;
+  DBuf<unsigned> split_ack, split_seen, split_xcc;
   DBuf<int> split_err;
   bool split_on = false;
 
@@ -514,17 +514,20 @@ struct nnsdp_solver {
     v_lds = proj_alg != nnsdp::kProjPacked && proj_lds_bytes(nsm, true, proj_alg) <= 160 * 1024;
     lds_bytes = proj_lds_bytes(nsm, v_lds, proj_alg);
     {
-      // two workgroups per block for the warm-start congruence: only where the second workgroup finds a free CU (one SDP's blocks;
-      // the batch handle fills the chip already and keeps the one-workgroup form).  OFF by default: built and measured slower -
-      // the congruence halves (30 900 -> ~17 000 cycles at n = 85) but the tiles' trip through L2 behind a release / acquire pair
-      // and the helper's later start cost more than that: 66.4 against 61.8 us per launch, 82.7 against 78.1 us per W40-D20 step
-      // (profiles/r04_split_probe.log; identical bits in all 36 probe cases)
-      int want = 0;
+      // two workgroups per block for the warm-start congruence (ProjArgs::split): only where the second workgroup finds a free CU (one
+      // SDP's blocks; the batch handle fills the chip already and keeps the one-workgroup form) and where it pays (a block above 80:
+      // six tile columns; at five and fewer the two forms tie - W40-D20 Double 57.8 / 58.3 us per step).  What the hand-over may cost
+      // decided everything: with an agent-scope fence in every wave and an acquire in every poll (an L2 write-back / invalidate each)
+      // the launch was SLOWER (66.4 against 61.8 us at n = 85); with workgroup-scope ordering only it was fast and WRONG under
+      // multi-process contention (the two-rank test saw stale tiles in 2 runs of 3: the pair does not always share an L2 then); with
+      // ONE agent-scope release behind the helper's barrier and ONE acquire fence after the leader's poll it is right and 3-4 us
+      // faster per launch (56.8 against 59.9 us, W40-D20 76.5 against 78.1 us per step; profiles/r04_split_probe.log)
+      int want = nsm > 80 ? 1 : 0;
       if (const char* e = std::getenv("NNSDP_SPLIT")) want = std::atoi(e);                              // (diagnostic override)
       split_on = want != 0 && proj_alg == nnsdp::kProjPingPong && v_lds && big_idx.empty() && ncl <= 120;
       if (split_on) {
         split_B.alloc((size_t)ncl * nnsdp::kSplitTileDoubles);
-        split_ack.alloc(ncl); split_ack.zero(); split_seen.alloc(ncl); split_seen.zero(); split_err.alloc(1); split_err.zero();
+        split_ack.alloc(ncl); split_ack.zero(); split_seen.alloc(ncl); split_seen.zero(); split_xcc.alloc(ncl); split_xcc.zero(); split_err.alloc(1); split_err.zero();
       }
     }
     // gather sources: entry e <- (clique k, lower element (i,j))
@@ -968,7 +971,7 @@ struct nnsdp_solver {
     a.refine = opt.proj_refine; a.rstate = d_rstate.p + 4 * k0; a.refine_acc = refine_acc; a.refine_kcap = refine_kcap; a.refine_loose = refine_loose; a.refine_k2cap = refine_k2cap; a.refine_pivots = refine_pivots; a.gram_credit = gram_credit;
     const bool use_pipe = warm && pipe_on && pipe.ready;
     if (split_on && warm && big_idx.empty()) {
-      a.split = 1; a.nblk = k1 - k0; a.sB = split_B.p; a.sack = split_ack.p; a.sseen = split_seen.p; a.serr = split_err.p; a.spin_limit = 20000000;
+      a.split = 1; a.nblk = k1 - k0; a.sB = split_B.p; a.sack = split_ack.p; a.sseen = split_seen.p; a.sxcc = split_xcc.p; a.serr = split_err.p; a.spin_limit = 20000000;
     }
     if (big_idx.empty()) {
       if (k1 > k0) {
@@ -1176,7 +1179,7 @@ struct nnsdp_solver {
     // rocSOLVER's convergence report of the library eigensolves, sticky since the solver was created.  Clique-sharded: only a block's
     // owner runs dsyevd, so the flag rides in the all-reduced control block (acc[7] >= 1024) and all ranks leave the loop together;
     // a rank-local exit would strand the others in the next iteration's all-reduce.
-    if (split_on && split_err.download()[0] != 0) throw HipError("projection kernel, two workgroups per block: a helper workgroup did not deliver its tiles in time");
+    if (split_on && split_err.download()[0] != 0) throw HipError("projection kernel, two workgroups per block: a helper workgroup did not deliver its tiles in time, or ran on another XCD than its leader");
     if (ipc && ipc_err.download()[0] != 0) throw HipError("clique-sharded exchange over hipIpc: a peer did not publish its partial sum in time (rank stopped or not co-scheduled)");
     if (!big_idx.empty()) {
       if (sharded) big_fail = big_fail || acc_host[7] >= 1024.0;
@@ -2329,11 +2332,11 @@ int nnsdp_project_psd_warm_state(int32_t batch, const int32_t* n, const double* 
   if (const char* e = std::getenv("NNSDP_REFINE_ACC")) a.refine_acc = std::atof(e);
   if (const char* e = std::getenv("NNSDP_REFINE_KCAP")) a.refine_kcap = std::atof(e);
   if (const char* e = std::getenv("NNSDP_REFINE_PIVOTS")) a.refine_pivots = std::atoi(e);
-  DBuf<double> sB; DBuf<unsigned> sack, sseen; DBuf<int> serr;
+  DBuf<double> sB; DBuf<unsigned> sack, sseen, sxcc; DBuf<int> serr;
   if (const char* e = std::getenv("NNSDP_SPLIT_WARM")) {       // (test hook) two workgroups per block, as a solver's warm launches run
     if (std::atoi(e) != 0 && alg == nnsdp::kProjPingPong && v_lds && batch <= 120) {
-      sB.alloc((size_t)batch * nnsdp::kSplitTileDoubles); sack.alloc(batch); sack.zero(); sseen.alloc(batch); sseen.zero(); serr.alloc(1); serr.zero();
-      a.split = 1; a.nblk = batch; a.sB = sB.p; a.sack = sack.p; a.sseen = sseen.p; a.serr = serr.p; a.spin_limit = 20000000;
+      sB.alloc((size_t)batch * nnsdp::kSplitTileDoubles); sack.alloc(batch); sack.zero(); sseen.alloc(batch); sseen.zero(); sxcc.alloc(batch); sxcc.zero(); serr.alloc(1); serr.zero();
+      a.split = 1; a.nblk = batch; a.sB = sB.p; a.sack = sack.p; a.sseen = sseen.p; a.sxcc = sxcc.p; a.serr = serr.p; a.spin_limit = 20000000;
     }
   }
   struct Events {

@@ -127,9 +127,11 @@ struct ProjArgs {
   double* sB;             // nblk x kSplitTileDoubles
   unsigned* sack;         // per block: exchanges completed by the helper
   unsigned* sseen;        // per block: exchanges consumed by the leader
+  unsigned* sxcc;         // per block: the XCD the helper ran on (diagnostic)
   int* serr;
   long long spin_limit;
 };
+static constexpr int kHwRegXccId = (3 << 11) | 20;     // s_getreg: 4 bits at offset 0 of HW_REG_XCC_ID (20): the XCD a wave runs on
 static constexpr int kSplitTileDoubles = 96 * 96;      // tile-ordered storage of one block's B (6 x 6 tiles of 256 doubles)
 
 // element (i,j) of the symmetric LDS matrix, lower triangle is the only copy that is kept current
@@ -423,13 +425,13 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k, const 
     // Jacobi sweeps read the lower triangle only).  Operand maps (verified on gfx950): lane l holds
     // A[l&15][l>>4], B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
     // part: 0 = the whole product; 1 / 2 = the leader's / the helper's tile columns of a split block (helper: columns 1 .. hc,
-    // leader: 0 and hc + 1 .. nt - 1 - the lower triangle's long columns are shared out: 9 + 12 tiles of 21 at nt = 6)
+    // leader: 0 and hc + 1 .. nt - 1; nt = 6: helper 12 tiles of T and 9 of B, leader 24 and 12)
     constexpr int NW = NT / 64;
     constexpr int MAXT = (NT == 512) ? 5 : 3;  // ceil(36 tiles / 16 waves), ceil(36 / 8), ceil(9 / 4)
     const int nt = npg >> 4, ks = (np + 3) >> 2;   // rows / columns past np are zero (identity in V): the K loop stops at np
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lc = lane >> 4;
-    const int hc = (nt + 1) >> 1;
+    const int hc = nt >= 6 ? nt / 3 : 1;        // (the helper gets LESS than half: its hand-over - stores, count, the leader's reads - runs while the leader still computes)
     const int ncol = part == 0 ? nt : part == 2 ? hc : nt - hc;
     auto colof = [&](int c) { return part == 0 ? c : part == 2 ? c + 1 : (c == 0 ? 0 : hc + c); };
     // lower tile number t of this part -> (ti, tj); false past the end
@@ -495,10 +497,16 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k, const 
       for (int m = 0; m < MAXT; ++m)
         if (tis[m] >= 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) out[(size_t)(tis[m] * nt + tjs[m]) * 256 + 64 * r + lane] = acc[m][r];
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(out + (size_t)(tis[m] * nt + tjs[m]) * 256 + 64 * r + lane, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-      __threadfence();
+      // (every element is an agent-scope store of its own - coherent at the device's memory side without an L2 write-back - so the
+      // hand-over only has to ORDER them in front of the count: wait for this wave's stores, meet the other waves, then count)
+      if (tid == 0) __hip_atomic_store(a.sxcc + k, (unsigned)__builtin_amdgcn_s_getreg(kHwRegXccId), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
+      // ONE agent-scope release for the whole workgroup (the barrier orders every wave's stores in front of it): the L2 write-back it
+      // implies is what a leader on ANOTHER XCD needs - under multi-process contention the pair does not always stay on one XCD
       if (tid == 0) __hip_atomic_store(a.sack + k, a.sack[k] + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
@@ -515,11 +523,13 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a, const int k, const 
       const unsigned want = a.sseen[k] + 1u;
       if (tid == 0) {
         long long spins = 0;
-        while (__hip_atomic_load(a.sack + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        while (__hip_atomic_load(a.sack + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > a.spin_limit) { atomicExch(a.serr, 1); break; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (one invalidate, after the count has arrived - not one per poll)
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       __syncthreads();
       const double* const in = a.sB + (size_t)k * kSplitTileDoubles;
       int nth = 0;
