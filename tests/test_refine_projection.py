@@ -380,3 +380,20 @@ def test_two_workgroups_per_block_give_identical_bits(n, monkeypatch):
         for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
             assert np.array_equal(a, b)
         assert list(out[0][2]) == list(out[1][2])
+
+
+def test_solver_iterates_do_not_depend_on_the_second_workgroup(monkeypatch):
+    """a solver whose launches hold a block above 80 shares the warm-start congruence of every block with a second workgroup
+    (NNSDP_SPLIT, default on there): 1 500 iterations of W40-D20 Single (blocks up to 85, checks, penalty changes, the refinement
+    stage coming in) must leave the same bits in the multiplier block with and without it"""
+    import hashlib
+    q = helpers.product_query(helpers.load_problem("W40-D20", 0))
+    dig = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("NNSDP_SPLIT", split)
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10 ** 9))
+        s.advance(1500)
+        res = s.residuals()
+        dig.append((hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest(), res))
+        s.close()
+    assert dig[0] == dig[1]
