@@ -332,7 +332,8 @@ struct nnsdp_solver {
   size_t lds_bytes = 0;
   int ldm = 0;
   // device state
-  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate, d_medrows, d_medsrc;
+  DBuf<int> d_cn, d_sptr, d_stats, d_long, d_rstate, d_medrows, d_medsrc, d_colcls;
+  int ncs = 0;                            // multipliers whose column of A holds at most kShortCol nonzeros (listed first in d_colcls)
   int nmed = 0, nmsrc = 0, nnz_A = 0;     // rows of A with 3 .. kLongRow nonzeros / pattern entries with more than two sources (16 lanes each)
   double refine_acc = 30.0, refine_kcap = 0.05, refine_loose = 1.0;
   // |K|_F^2 above which the refinement step is not taken (NNSDP_REFINE_KMAX overrides |K|_F).  Round 3 had 0.09 (|K|_F <= 0.3, from the
@@ -593,6 +594,13 @@ struct nnsdp_solver {
       if (mr.empty()) mr.push_back(0);
       if (ms.empty()) ms.push_back(0);
       d_medrows.upload(mr); d_medsrc.upload(ms);
+      std::vector<int> cc;
+      cc.reserve(S.ng + 1);
+      for (int g = 0; g < S.ng; ++g) if (S.csc_ptr[g + 1] - S.csc_ptr[g] <= nnsdp::kShortCol) cc.push_back(g);
+      ncs = (int)cc.size();
+      for (int g = 0; g < S.ng; ++g) if (S.csc_ptr[g + 1] - S.csc_ptr[g] > nnsdp::kShortCol) cc.push_back(g);
+      if (cc.empty()) cc.push_back(0);
+      d_colcls.upload(cc);
     }
     // M^-1 on the device (rocSOLVER potrf + potri; one-time plain-library factorisation)
     roc.reset(new RocHandle());
@@ -1030,8 +1038,11 @@ struct nnsdp_solver {
       hipLaunchKernelGGL(k_gather_g, dim3(nshort + cdiv((long long)nmsrc * 16, kThreads)), dim3(kThreads), 0, st, nshort, NE, d_sptr.p, d_soff.p, d_isdiag.p,
                          nu.p + ng, w.p + ng, D.z0.p, D.Dinv.p, d_sigma(), g.p, d_medsrc.p, nmsrc);
     }
-    hipLaunchKernelGGL(k_spmv_At, dim3(cdiv((long long)ng * 64, kThreads)), dim3(kThreads), 0, st, ng, D.csc_ptr.p, D.csc_row.p,
-                       D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p);
+    {
+      const int nsb = cdiv((long long)ncs * 16, kThreads);
+      hipLaunchKernelGGL(k_spmv_At, dim3(std::max(nsb + cdiv((long long)(ng - ncs) * 64, kThreads), 1)), dim3(kThreads), 0, st, nsb, ng, D.csc_ptr.p, D.csc_row.p,
+                         D.csc_val.p, g.p, nu.p, D.c.p, d_kappa(), p.p, qv.p, d_colcls.p, ncs);
+    }
     if (check) {
       if (sharded) {
         exchange_h(1);
@@ -1671,7 +1682,7 @@ struct nnsdp_batch {
   int nblocks = 0, nmax = 0, alg = 0;
   bool v_lds = true, any_structured = false, any_big = false;
   size_t lds = 0;
-  int gx_gather = 0, gx_gather_med = 0, gx_at = 0, gx_gemv = 0, gx_ax = 0, gx_ax_med = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
+  int gx_gather = 0, gx_gather_med = 0, gx_at_s = 0, gx_at_l = 0, gx_gemv = 0, gx_ax = 0, gx_ax_med = 0, gx_long = 0, gx_upd = 0, gx_tiles = 0, gx_nb = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   static constexpr int kGraphIters = 8;
@@ -1709,7 +1720,7 @@ struct nnsdp_batch {
     std::vector<IterArgs> it;
     std::vector<ProjArgs> pw, pc;
     std::vector<int2> map;
-    nmax = 0; gx_gather = gx_gather_med = gx_at = gx_gemv = gx_ax = gx_ax_med = gx_long = gx_upd = gx_tiles = gx_nb = 0;
+    nmax = 0; gx_gather = gx_gather_med = gx_at_s = gx_at_l = gx_gemv = gx_ax = gx_ax_med = gx_long = gx_upd = gx_tiles = gx_nb = 0;
     any_structured = false; any_big = false;
     for (size_t b = 0; b < act.size(); ++b) {
       nnsdp_solver* s = act[b];
@@ -1723,6 +1734,7 @@ struct nnsdp_batch {
       a.csr_ptr = s->D.csr_ptr.p; a.csr_col = s->D.csr_col.p; a.csr_val = s->D.csr_val.p;
       a.longrows = s->d_long.p; a.gidx = s->d_gidx.p;
       a.medrows = s->d_medrows.p; a.medsrc = s->d_medsrc.p; a.nmed = s->nmed; a.nmsrc = s->nmsrc; a.nnz = s->nnz_A;
+      a.colcls = s->d_colcls.p; a.ncs = s->ncs;
       a.z0 = s->D.z0.p; a.Dinv = s->D.Dinv.p; a.c = s->D.c.p; a.Minv = s->Minv.p;
       a.nu = s->nu.p; a.w = s->w.p; a.g = s->g.p; a.p = s->p.p; a.qv = s->qv.p; a.ww = s->ww.p; a.x = s->x.p;
       a.sigma = s->d_sigma(); a.kappa = s->d_kappa(); a.alpha = s->opt.alpha;
@@ -1756,8 +1768,9 @@ struct nnsdp_batch {
       gx_gather = std::max(gx_gather, cdiv(a.NE, kThreads));
       gx_gather_med = std::max(gx_gather_med, cdiv((long long)a.nmsrc * 16, kThreads));
       gx_ax_med = std::max(gx_ax_med, cdiv((long long)a.nmed * 16, kThreads));
-      gx_at = std::max(gx_at, cdiv((long long)a.ng * 64, kThreads));
-      gx_gemv = gx_at;
+      gx_at_s = std::max(gx_at_s, cdiv((long long)a.ncs * 16, kThreads));
+      gx_at_l = std::max(gx_at_l, cdiv((long long)(a.ng - a.ncs) * 64, kThreads));
+      gx_gemv = std::max(gx_gemv, cdiv((long long)a.ng * 64, kThreads));
       gx_ax = std::max(gx_ax, cdiv(a.NE, kThreads));
       gx_long = std::max(gx_long, a.nlong);
       gx_upd = std::max(gx_upd, cdiv(a.ng + a.nmat, kThreads));
@@ -1781,7 +1794,7 @@ struct nnsdp_batch {
     if (nblocks > 0) launch_proj_batched(warm ? d_pw.p : d_pc.p, d_map.p, nblocks, nmax, v_lds, lds, st, alg);
     if (any_big) for (nnsdp_solver* s : act) s->enqueue_big_blocks(st);
     hipLaunchKernelGGL(k_gather_g_b, dim3(gx_gather + gx_gather_med, B), dim3(kThreads), 0, st, d_it.p, gx_gather);
-    hipLaunchKernelGGL(k_spmv_At_b, dim3(gx_at, B), dim3(kThreads), 0, st, d_it.p);
+    hipLaunchKernelGGL(k_spmv_At_b, dim3(std::max(gx_at_s + gx_at_l, 1), B), dim3(kThreads), 0, st, d_it.p, gx_at_s);
     static const bool full_gemv = [] { const char* e = std::getenv("NNSDP_BATCH_FULL_GEMV"); return e && std::atoi(e) != 0; }();   // diagnostic
     if (any_structured) { for (nnsdp_solver* s : act) s->enqueue_minv(st); }     // large multiplier counts: each SDP's structured M^-1
     else if (full_gemv) hipLaunchKernelGGL(k_gemv_sym_b, dim3(gx_gemv, B), dim3(kThreads), 0, st, d_it.p);

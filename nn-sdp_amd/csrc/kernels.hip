@@ -2610,6 +2610,7 @@ struct IterArgs {
   const int* csr_ptr; const int* csr_col; const double* csr_val;
   const int* longrows; const unsigned int* gidx;
   const int* medrows; const int* medsrc; int nmed, nmsrc, nnz;   // rows of A with 3 .. kLongRow nonzeros / pattern entries with more than 2 sources
+  const int* colcls; int ncs;                                      // multipliers by column length: the first ncs of colcls have <= kShortCol nonzeros
   const double* z0; const double* Dinv; const double* c; const double* Minv;
   double* nu; double* w; double* g; double* p; double* qv; double* ww; double* x;
   const double* sigma; double* kappa;
@@ -2621,32 +2622,59 @@ struct IterArgs {
 // multiplier block: w_s = max(nu_s, 0), reflection p = 2 w_s - nu_s - c   (also applies kappa)
 // fused into the A' product: qv[g] = sum_e A[e,g] gvec[e] - p[g]; one wave per multiplier.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spmv_At_body(const int bid, int ng, const int* __restrict__ ptr, const int* __restrict__ row,
+// Columns of A (one per multiplier) by length (round 4): two thirds of them hold at most 64 nonzeros - a wave per column left most lanes
+// idle and, in the batch handle, 29 k waves for three dependent round trips each (16.9 us for 13 SDPs).  Columns of up to kShortCol
+// nonzeros take 16 lanes (blocks [0, nsb): 16 columns per workgroup, the whole column in flight at once), the others a wave with four
+// chunks of 64 in flight; colcls lists the short ones first.
+static constexpr int kShortCol = 64;
+__device__ __forceinline__ void spmv_At_body(const int bid, const int nsb, int ng, const int* __restrict__ ptr, const int* __restrict__ row,
                                                        const double* __restrict__ val, const double* __restrict__ gvec,
                                                        double* __restrict__ nus, const double* __restrict__ c,
                                                        const double* __restrict__ kappa, double* __restrict__ p,
-                                                       double* __restrict__ qv) {
-  int g = (bid * kThreads + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (g >= ng) return;
-  // (everything lane 0 needs at the end is requested before the column loop: a dependent round trip less per wave)
+                                                       double* __restrict__ qv, const int* __restrict__ colcls, const int ncs) {
+  int g, lane;
+  double s = 0.0;
+  const bool shortc = bid < nsb;
+  if (shortc) {
+    const int gi = bid * (kThreads / 16) + (threadIdx.x >> 4);
+    lane = threadIdx.x & 15;
+    if (gi >= ncs) return;            // (whole 16-lane groups leave together: the DPP row sums below stay inside a group)
+    g = colcls[gi];
+  } else {
+    const int wi = (bid - nsb) * (kThreads / 64) + (threadIdx.x >> 6);
+    lane = threadIdx.x & 63;
+    if (wi >= ng - ncs) return;
+    g = colcls[ncs + wi];
+  }
+  // (everything lane 0 needs at the end is requested before the column loop: a dependent round trip less)
   const double v0 = nus[g], cg = c[g];
   const double kap = kappa ? *kappa : 1.0;
-  // (a tenth of the columns hold 250 .. 530 nonzeros - the sector multipliers' W' diag W blocks: four chunks of 64 are requested
-  // together, index / value loads first and the gathers behind them, instead of one dependent chain per chunk)
-  double s = 0.0;
-  const int q1 = ptr[g + 1];
-  for (int q = ptr[g] + lane; q < q1; q += 256) {
+  const int q0 = ptr[g], q1 = ptr[g + 1];
+  if (shortc) {
     double vv[4]; int rr[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int qq = min(q + 64 * u, q1 - 1); vv[u] = val[qq]; rr[u] = row[qq]; }
+    for (int u = 0; u < 4; ++u) { const int qq = max(min(q0 + lane + 16 * u, q1 - 1), 0); vv[u] = val[qq]; rr[u] = row[qq]; }      // (an empty column reads a neighbour's entry and discards it)
     double gg[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) gg[u] = gvec[rr[u]];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s += (q + 64 * u < q1) ? vv[u] * gg[u] : 0.0;
+    for (int u = 0; u < 4; ++u) s += (q0 + lane + 16 * u < q1) ? vv[u] * gg[u] : 0.0;
+    s = row_sum16(s);
+  } else {
+    // (a tenth of the columns hold 250 .. 530 nonzeros - the sector multipliers' W' diag W blocks: four chunks of 64 are requested
+    // together, index / value loads first and the gathers behind them, instead of one dependent chain per chunk)
+    for (int q = q0 + lane; q < q1; q += 256) {
+      double vv[4]; int rr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int qq = min(q + 64 * u, q1 - 1); vv[u] = val[qq]; rr[u] = row[qq]; }
+      double gg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gg[u] = gvec[rr[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (q + 64 * u < q1) ? vv[u] * gg[u] : 0.0;
+    }
+    s = wave_sum(s);
   }
-  s = wave_sum(s);
   if (lane == 0) {
     double v = v0, wv = v > 0.0 ? v : 0.0;
     if (kap != 1.0) { v = wv + kap * (v - wv); nus[g] = v; }
@@ -2655,15 +2683,16 @@ __device__ __forceinline__ void spmv_At_body(const int bid, int ng, const int* _
     qv[g] = s - pp;
   }
 }
-__global__ __launch_bounds__(kThreads) void k_spmv_At(int ng, const int* __restrict__ ptr, const int* __restrict__ row,
+__global__ __launch_bounds__(kThreads) void k_spmv_At(int nsb, int ng, const int* __restrict__ ptr, const int* __restrict__ row,
                                                        const double* __restrict__ val, const double* __restrict__ gvec,
                                                        double* __restrict__ nus, const double* __restrict__ c,
                                                        const double* __restrict__ kappa, double* __restrict__ p,
-                                                       double* __restrict__ qv) { spmv_At_body(blockIdx.x, ng, ptr, row, val, gvec, nus, c, kappa, p, qv); }
-__global__ __launch_bounds__(kThreads) void k_spmv_At_b(const IterArgs* __restrict__ A) {
+                                                       double* __restrict__ qv, const int* __restrict__ colcls, int ncs) {
+  spmv_At_body(blockIdx.x, nsb, ng, ptr, row, val, gvec, nus, c, kappa, p, qv, colcls, ncs);
+}
+__global__ __launch_bounds__(kThreads) void k_spmv_At_b(const IterArgs* __restrict__ A, const int nsb_max) {
   const IterArgs a = A[blockIdx.y];
-  if ((long long)blockIdx.x * kThreads >= (long long)a.ng * 64) return;
-  spmv_At_body(blockIdx.x, a.ng, a.csc_ptr, a.csc_row, a.csc_val, a.g, a.nu, a.c, a.kappa, a.p, a.qv);
+  spmv_At_body(blockIdx.x, nsb_max, a.ng, a.csc_ptr, a.csc_row, a.csc_val, a.g, a.nu, a.c, a.kappa, a.p, a.qv, a.colcls, a.ncs);
 }
 
 // g[e] = Dinv[e] (z0[e] / sigma + wgt * sum_src (2 w - nu)[src]); kGatherLanes lanes per pattern entry: the entries of the
