@@ -446,15 +446,19 @@ def main():
         sw.advance(args.wide_burn_in)
         sw.iterate(16, time_eig=True)
         dev_sync()
+        # 2 000 steps: a launch in which one 151-block falls back to the packed sweeps lasts ~1 ms against ~0.19 ms when every block takes
+        # the refinement step, and on this network about one visit in ten still falls back - a 200-step window (rounds 3 and 4 until
+        # the last day) read 193 us or 1 051 us depending on where it fell
+        wsteps = 2000
         t1 = time.perf_counter()
-        msw = sw.iterate(200, time_eig=True)
+        msw = sw.iterate(wsteps, time_eig=True)
         dev_sync()
         dtw = time.perf_counter() - t1
         smw = sw.finish().summary
         sw.close()
         out["wide_blocks"] = {"workload": "ACAS-Xu shaped 5-50x6-5 (random weights), reach hyperplane, interval arithmetic, SingleDecomp",
-                              "blocks": smw["n_cliques"], "max_block": smw["max_clique"], "burn_in_iters": args.wide_burn_in, "steps": 200,
-                              "iters_per_s": 200 / dtw, "kernel_avg_us": 1e3 * msw / 200, "refine_blocks": smw["refine_blocks"],
+                              "blocks": smw["n_cliques"], "max_block": smw["max_clique"], "burn_in_iters": args.wide_burn_in, "steps": wsteps,
+                              "iters_per_s": wsteps / dtw, "kernel_avg_us": 1e3 * msw / wsteps, "refine_blocks": smw["refine_blocks"],
                               "note": "one GPU, eager launches with per-launch events like `value` (the events bracket the five k_pipe_* launches + k_proj_jacobi); not BASELINE's metric config"}
         if args.cert_seconds > 0:
             # whole solves of the same query to residuals 1e-5: the reference's cliques, and the decomposition AutoDecomp picks (path cliques 6 x 101)
@@ -463,7 +467,7 @@ def main():
                 s3 = na.runQuery(qw, na.AdmmSdpOptions(decomp_mode=mode, max_iters=300000, eps_rel=1e-5, max_time=args.cert_seconds))
                 out["wide_blocks"][label] = {"wall_s": time.perf_counter() - t2, "solve_s": s3.solve_time, "status": s3.termination_status, "iters": s3.summary["iters"],
                                              "bound": s3.objective_value, "blocks": s3.summary["n_cliques"], "max_block": s3.summary["max_clique"],
-                                             "lambda_max": s3.summary["lambda_max"]}
+                                             "lambda_max": s3.summary["lambda_max"], "us_per_iter": 1e6 * s3.solve_time / max(s3.summary["iters"], 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         need = None
         if "time_to_cert" in out:
