@@ -62,6 +62,7 @@ struct PipeArgs {
   double* psum;             // [block][pt][8] partial sums of the lower tiles: off2, k2, unpp, unnn, unx, kd2, r2
   int* vrec;                // [block][4] snapshot of rstate taken by P1: word, do_gram, rdef (double)
   int* pmode;               // [block] 0: not handled (the one-CU kernel runs it), 1: stepped, 2: converged as it arrived
+  int* again;               // [block] written by pass 0's P5: 1 = the block took a BLIND step (below) and pass 1 analyses it afresh
   int* rstate;              // refinement state per block (ProjArgs::rstate)
   int* stats;               // ProjArgs::stats
   const double* kappa;      // device scalar, may be null
@@ -69,6 +70,13 @@ struct PipeArgs {
   double tol;
   double refine_acc, refine_kcap, refine_loose, refine_k2cap;
   int gram_credit;
+  // Second pass (near misses).  A block whose prediction misses the accepted level by less than `refine_near` x takes the step anyway -
+  // the basis is updated, nothing else - and the five launches run once more for exactly those blocks (pass = 1): second-order
+  // convergence makes the second analysis pass by a wide margin, at the price of one more pipeline pass (~60 us) instead of the
+  // packed sweeps (~1 ms for a 151-block).  The second pass decides by its own measured numbers (Gram product forced), so
+  // nothing rests on the first prediction; a block it rejects goes to the one-CU kernel as before.
+  double refine_near;       // <= 1: off
+  int pass;                 // 0 / 1
   int vs;                   // stride of the per-block vectors (multiple of 16, >= largest block)
   int pt;                   // stride of psum in tiles (>= lower tiles of the largest block)
   int rows;                 // tile rows per row group (<= kPipeWaves; fewer when the strips of the largest block would not fit LDS)
@@ -89,7 +97,7 @@ struct PipeArgs {
 #endif
 
 struct PipeDecision {
-  int mode;                 // 0 not handled, 1 step, 2 converged as it arrived
+  int mode;                 // 0 not handled, 1 step, 2 converged as it arrived, 3 (pass 0 only) blind step: basis updated, analysed again in pass 1
   bool up;                  // rebuild W from the positive side
   bool loose, do_gram;
   double r2, k2, rdef;
@@ -160,6 +168,7 @@ __device__ __forceinline__ PipeDecision pipe_decide(const PipeArgs& a, const int
     else if (kok && (prefer_pos ? pred_neg : pred_pos) <= accT) side = prefer_pos ? -1 : 1;
     else if (kok && D.credit >= 16 && fmin(pred_pos, pred_neg) <= a.refine_loose * accT) { side = pred_pos <= pred_neg ? 1 : -1; D.loose = true; }
     if (side != 0) { D.mode = 1; D.up = side > 0; }
+    else if (a.pass == 0 && kok && fmin(pred_pos, pred_neg) <= a.refine_near * accT) { D.mode = 3; D.up = pred_pos <= pred_neg; }      // blind step, second pass
   }
   return D;
 }
@@ -269,6 +278,7 @@ __device__ __forceinline__ d4_t pipe_chain_scaled(const double* __restrict__ SA,
   const PipeWg m = a.wgmap[blockIdx.x];                                                                    \
   const int b = m.b, tj = m.tj;                                                                            \
   if (b < 0) return;                                                                                       \
+  if (a.pass == 1 && a.again[b] == 0) return;                                                              \
   const int n = a.cn[b], nt = (n + 15) >> 4, ksq = (n + 3) >> 2, kp = 4 * ksq, ng = (nt + a.rows - 1) / a.rows; \
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lc = lane >> 4;                \
   const int ti = m.r0 + wv;                                                                                \
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(64 * kPipeWaves) void k_pipe_X(PipeArgs a) {
     rec->credit = D.credit; rec->gcred = D.gcred; rec->r2 = D.r2; rec->k2 = D.k2; rec->rdef = D.rdef;
     rec->off2 = D.off2; rec->unpp = D.unpp; rec->unnn = D.unnn; rec->unx = D.unx; rec->kd2 = D.kd2; rec->accT = D.accT;
   }
-  if (D.mode != 1) return;                 // (uniform over the workgroup)
+  if (D.mode != 1 && D.mode != 3) return;  // (uniform over the workgroup)
   pipe_strip_store(pe, G, SE, n, 16 * tj);
   pipe_strip_store(pet, G, SEt, n, 16 * tj);
 #pragma unroll
@@ -659,7 +669,24 @@ __global__ __launch_bounds__(64 * kPipeWaves) void k_pipe_W(PipeArgs a) {
   PST(4, 0)
   const PipeRec rec = reinterpret_cast<const PipeRec*>(a.drec)[b];
   const bool writer = tj == 0 && m.r0 == 0 && wv == 0;
-  if (rec.mode == 0) { if (writer && lane == 0) a.pmode[b] = 0; return; }      // (uniform over the workgroup)
+  if (rec.mode == 0) { if (writer && lane == 0) { a.pmode[b] = 0; if (a.pass == 0) a.again[b] = 0; } return; }      // (uniform over the workgroup)
+  if (rec.mode == 3) {
+    // blind step: the new basis becomes the persistent one (U and Vg share their layout: the workgroups of the first row group copy
+    // their tile column's 16 columns), the state asks the second pass for a Gram visit, nothing is projected
+    if (m.r0 == 0) {
+      const double* Uc = a.U + a.coff[b];
+      double* vg = a.Vg + a.coff[b];
+      const int e0 = 16 * tj * n, e1 = min(16 * (tj + 1), n) * n;
+      for (int e = e0 + (int)threadIdx.x; e < e1; e += (int)blockDim.x) vg[e] = Uc[e];
+    }
+    if (writer && lane == 0) {
+      a.rstate[4 * b] = (rec.credit << 16);                  // no back-off, Gram credit 0: the second pass measures V'V
+      *reinterpret_cast<double*>(a.rstate + 4 * b + 2) =
+          (rec.do_gram ? rec.r2 + 2.0 * sqrt(rec.r2 * rec.k2) : rec.rdef * (1.0 + 2.2 * sqrt(rec.k2))) + 0.25 * rec.k2 * rec.k2;
+      a.pmode[b] = 0; a.again[b] = 1;
+    }
+    return;
+  }
   if (m.r0 + m.rw <= tj) return;
   const double* Uk = a.U + a.coff[b];
   double* nuk = a.nu + a.coff[b];
@@ -777,6 +804,7 @@ __global__ __launch_bounds__(64 * kPipeWaves) void k_pipe_W(PipeArgs a) {
     a.rstate[4 * b] = word | ((rec.do_gram ? a.gram_credit : rec.gcred - 1) << 24);
     *reinterpret_cast<double*>(a.rstate + 4 * b + 2) = rnew;
     a.pmode[b] = rec.mode;
+    if (a.pass == 0) a.again[b] = 0;
   }
   PST(4, 4)
 }
@@ -791,16 +819,17 @@ struct RefinePipe {
   PipeWg* wgmap = nullptr;
   double *T = nullptr, *E = nullptr, *U = nullptr, *Vt = nullptr, *Et = nullptr, *drec = nullptr, *dpart = nullptr, *rdg = nullptr, *lpart = nullptr, *frop = nullptr,
          *psum = nullptr;
-  int *vrec = nullptr, *pmode = nullptr;
+  int *vrec = nullptr, *pmode = nullptr, *again = nullptr;
+  double near = 10.0;        // PipeArgs::refine_near (NNSDP_PIPE_NEAR; <= 1: one pass only)
   bool ready = false;
   RefinePipe() = default;
   RefinePipe(const RefinePipe&) = delete;            // (owns device memory)
   RefinePipe& operator=(const RefinePipe&) = delete;
   ~RefinePipe() { release(); }
   void release() {
-    void* ps[] = {wgmap, T, E, U, Vt, Et, drec, dpart, rdg, lpart, frop, psum, vrec, pmode};
+    void* ps[] = {wgmap, T, E, U, Vt, Et, drec, dpart, rdg, lpart, frop, psum, vrec, pmode, again};
     for (void* p : ps) if (p) (void)hipFree(p);
-    wgmap = nullptr; T = E = U = Vt = Et = drec = dpart = rdg = lpart = frop = psum = nullptr; vrec = pmode = nullptr; ready = false;
+    wgmap = nullptr; T = E = U = Vt = Et = drec = dpart = rdg = lpart = frop = psum = nullptr; vrec = pmode = again = nullptr; ready = false;
   }
   // LDS bytes of a launch whose largest block is nmax with `r` tile rows per group: P2 / P3 hold (r + 2) strips, P1 the stride-17
   // strip + r strips, P4 / P5 (r + 1) strips; reduction scratch and the eigenvalue weights behind them
@@ -850,7 +879,8 @@ struct RefinePipe {
     al((void**)&Vt, ((size_t)nmat + 16) * 8); al((void**)&Et, ((size_t)nmat + 16) * 8); al((void**)&drec, (size_t)nb * sizeof(PipeRec));
     al((void**)&dpart, (size_t)nb * kMaxGroups * vs * 8); al((void**)&rdg, (size_t)nb * vs * 8); al((void**)&lpart, (size_t)nb * kMaxGroups * vs * 4 * 8);
     al((void**)&frop, (size_t)nb * 16 * 8); al((void**)&psum, (size_t)nb * pt * 8 * 8);
-    al((void**)&vrec, (size_t)nb * 4 * sizeof(int)); al((void**)&pmode, (size_t)nb * sizeof(int));
+    al((void**)&vrec, (size_t)nb * 4 * sizeof(int)); al((void**)&pmode, (size_t)nb * sizeof(int)); al((void**)&again, (size_t)nb * sizeof(int));
+    if (const char* e = std::getenv("NNSDP_PIPE_NEAR")) near = std::atof(e);                                        // (diagnostic)
     if (e == hipSuccess) e = hipMemcpy(wgmap, map.data(), map.size() * sizeof(PipeWg), hipMemcpyHostToDevice);
     if (lds > 64 * 1024) {
       const void* ks[] = {(const void*)&k_pipe_T, (const void*)&k_pipe_B, (const void*)&k_pipe_X, (const void*)&k_pipe_V, (const void*)&k_pipe_W};
@@ -864,7 +894,7 @@ struct RefinePipe {
     PipeArgs a{};
     a.cn = p.cn; a.coff = p.coff; a.wgmap = wgmap; a.nu = p.nu; a.w = p.w; a.Vg = p.Vg;
     a.T = T; a.E = E; a.U = U; a.Vt = Vt; a.Et = Et; a.drec = drec; a.dpart = dpart; a.rdg = rdg; a.lpart = lpart; a.frop = frop; a.psum = psum;
-    a.vrec = vrec; a.pmode = pmode;
+    a.vrec = vrec; a.pmode = pmode; a.again = again; a.refine_near = near; a.pass = 0;
     a.rstate = p.rstate; a.stats = p.stats; a.kappa = p.kappa; a.tol_dev = p.tol_dev; a.tol = p.tol;
     a.refine_acc = p.refine_acc; a.refine_kcap = p.refine_kcap; a.refine_loose = p.refine_loose; a.refine_k2cap = p.refine_k2cap; a.gram_credit = p.gram_credit;
     a.vs = vs; a.pt = pt; a.rows = rows; a.eig = p.eig; a.eoff = p.eoff;
@@ -872,11 +902,15 @@ struct RefinePipe {
   }
   void launch(const PipeArgs& a, hipStream_t st) const {
     const dim3 g(nwg), t(64 * kPipeWaves);
-    hipLaunchKernelGGL(k_pipe_T, g, t, lds, st, a);
-    hipLaunchKernelGGL(k_pipe_B, g, t, lds, st, a);
-    hipLaunchKernelGGL(k_pipe_X, g, t, lds, st, a);
-    hipLaunchKernelGGL(k_pipe_V, g, t, lds, st, a);
-    hipLaunchKernelGGL(k_pipe_W, g, t, lds, st, a);
+    PipeArgs b = a;
+    for (int pass = 0; pass < (a.refine_near > 1.0 ? 2 : 1); ++pass) {
+      b.pass = pass;
+      hipLaunchKernelGGL(k_pipe_T, g, t, lds, st, b);
+      hipLaunchKernelGGL(k_pipe_B, g, t, lds, st, b);
+      hipLaunchKernelGGL(k_pipe_X, g, t, lds, st, b);
+      hipLaunchKernelGGL(k_pipe_V, g, t, lds, st, b);
+      hipLaunchKernelGGL(k_pipe_W, g, t, lds, st, b);
+    }
   }
 };
 
