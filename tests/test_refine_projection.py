@@ -397,3 +397,27 @@ def test_solver_iterates_do_not_depend_on_the_second_workgroup(monkeypatch):
         dig.append((hashlib.sha256(s.raw_multipliers().tobytes()).hexdigest(), res))
         s.close()
     assert dig[0] == dig[1]
+
+
+@pytest.mark.parametrize("n", [85, 151])
+def test_pipeline_second_pass_takes_near_misses(n, monkeypatch):
+    """a move whose predicted error misses the accepted level by a small factor: with one pass the pipeline hands the block to the
+    kernel behind it (sweeps), with the second pass (default) the block takes the step blind, is analysed again on its own measured
+    numbers and is carried - inside the level the stage promises either way"""
+    rng = np.random.default_rng(500 + n)
+    spec = np.concatenate([np.linspace(0.2, 2.0, n - n // 3), -np.linspace(0.1, 1.5, n // 3)])
+    base = [_sym(rng, n, spec) for _ in range(3)]
+    tol = 3e-7
+    found = False
+    for eta in (2e-4, 4e-4, 8e-4, 1.6e-3):
+        mats = [_perturb(rng, A, eta) for A, _ in base]
+        out = {}
+        for near in ("0", "10"):
+            monkeypatch.setenv("NNSDP_PIPE_NEAR", near)
+            out[near] = na.project_psd_warm(mats, [Q for _, Q in base], tol, refine=4)
+            for A, Wk, Vk in zip(mats, out[near][0], out[near][1]):
+                assert np.linalg.norm(Wk - oadmm.project_psd(A)) <= 30 * tol * np.linalg.norm(A), (eta, near)
+                assert np.linalg.norm(Vk.T @ Vk - np.eye(n)) <= 1e-6
+        if out["0"][2][1] == 0 and out["10"][2][1] == 3:      # one pass: no block stepped; two passes: all three did
+            found = True
+    assert found
