@@ -9,7 +9,7 @@ xi, acx = F.intervalsWorstCase(lo, hi, net)
 nrm = np.zeros(5); nrm[0] = 1.0
 q = na.ReachQuery(ffnet=net, qc_input=na.QcInputBox(x1min=lo, x1max=hi), qc_reach=na.QcReachHplane(normal=nrm), qc_activs=F.makeQcActivsIntvs(net, xi, acx, 0))
 s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.SingleDecomp(), max_iters=10**9))
-for upto in (3000, 3001, 3002, 3003, 3004, 3005, 3006, 3007, 9000, 9001, 9002, 9003, 9004, 9005):
+for upto in list(range(9000, 9120)):
     s.advance(upto - int(s.info(3)))
     print("== iteration", int(s.info(3)), flush=True)
     s.finish()
