@@ -126,7 +126,9 @@ typedef struct nnsdp_options {
                              A launch that holds a block above 96 runs the same stage as FIVE short launches over the whole chip
                              (tile-parallel pipeline, csrc/refine_pipe.hpp: workgroup = (block, tile column, row group)) in front of the
                              one-CU kernel, which then only sees the blocks the pipeline did not carry; it switches itself on once 70 % of
-                             a check window's block visits took the step and off below 40 % (width-50 networks: 2.1x per solve).  Launches
+                             a check window's block visits took the step and off below 40 % (width-50 networks: 2.1x per solve); a block
+                             whose prediction misses the accepted level by less than 10x takes the step anyway and is analysed afresh by a
+                             second pass of the five launches instead of going to the sweeps (another 1.5x on such networks).  Launches
                              of blocks up to 96 keep the one-CU form (the five launches tie with it there: DESIGN.md section 4). */
 } nnsdp_options;
 
