@@ -74,6 +74,20 @@ def test_published_objective_within_the_stated_tolerance(name, beta, measured):
     assert rel <= TOL * abs(s.objective_value) + 1e-9, (name, beta, s.objective_value, pub, rel / abs(s.objective_value))
 
 
+@pytest.mark.parametrize("name,beta,measured", [(n, b, m) for n, b, m in ROWS if m])
+def test_rows_outside_the_tolerance_sit_where_they_were_recorded(name, beta, measured):
+    """ what IS claimed about the 14 rows above, as assertions that pass: the certified value is BELOW every published
+    value (one-signed: ours is the tighter bound) and its relative distance to the nearest one is the recorded one within a band -
+    so that a change which moves a row shows up here as a failure with numbers, not only as an unexpected pass of a strict xfail"""
+    q, s = _solve_all()[(name, beta)]
+    pub = helpers.published_rho(name, beta)
+    rho = s.objective_value
+    assert s.termination_status == "OPTIMAL"
+    assert rho < min(pub), (name, beta, rho, pub)
+    rel = min(abs(rho - p) for p in pub) / abs(rho)
+    assert abs(rel - measured) <= 0.15 * measured + 2e-4, (name, beta, rel, measured)
+
+
 @pytest.mark.parametrize("name,beta", [(n, b) for n, b, _ in ROWS])
 def test_certificate_is_sound_feasible_and_never_looser_than_the_reference(name, beta):
     q, s = _solve_all()[(name, beta)]
