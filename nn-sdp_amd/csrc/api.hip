@@ -616,12 +616,12 @@ struct nnsdp_solver {
     }
     if (minv_structured) { build_structured_minv(); lap("structured M^-1"); }
     else {
-      std::vector<double> M;
-      build_M(S, M);
+      std::unique_ptr<double[]> M(new double[(size_t)std::max(ng, 1) * std::max(ng, 1)]);      // (not initialised: the builder's threads touch it first)
+      build_M_lower(S, M.get());
       lap("M = I + A'D^-1A (host)");
       Minv.alloc((size_t)ldm * std::max(ng, 1));
       Minv.zero();
-      HIPCHK(hipMemcpy2D(Minv.p, (size_t)ldm * sizeof(double), M.data(), (size_t)ng * sizeof(double), (size_t)ng * sizeof(double),
+      HIPCHK(hipMemcpy2D(Minv.p, (size_t)ldm * sizeof(double), M.get(), (size_t)ng * sizeof(double), (size_t)ng * sizeof(double),
                          ng, hipMemcpyHostToDevice));
     lap("M upload");
     DBuf<rocblas_int> info;

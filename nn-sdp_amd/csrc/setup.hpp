@@ -13,10 +13,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nnsdp.h"
@@ -590,23 +593,38 @@ inline ScaledOperator scale_operator(const Operator& op, bool normalize_columns,
 }
 
 // dense M = I + A' D^-1 A (column-major ng x ng, both triangles)
-inline void build_M(const ScaledOperator& S, std::vector<double>& M) {
-  size_t n = S.ng;
-  M.assign(n * n, 0.0);
-  for (int e = 0; e < S.NE; ++e) {
-    int lo = S.csr_ptr[e], hi = S.csr_ptr[e + 1];
-    double d = S.Dinv[e];
-    for (int x = lo; x < hi; ++x) {
-      double vx = d * S.csr_val[x];
-      size_t cx = S.csr_col[x];
-      double* col = &M[cx * n];
-      for (int y = x; y < hi; ++y) col[S.csr_col[y]] += vx * S.csr_val[y];  // lower: row >= col (cols sorted)
+// M = I + A' D^-1 A, dense, LOWER triangle (column-major, leading dimension ng; the upper triangle is zero: the device factorises with
+// fill_lower and mirrors the inverse itself) into caller memory that need not be initialised.  Host threads own disjoint column ranges:
+// every entry is accumulated by ONE thread in the row order of A, so the bits do not depend on the thread count; each thread also
+// first-touches its own columns (W40-D40, 150 MB: 31 ms -> see DESIGN.md section 5).
+inline void build_M_lower(const ScaledOperator& S, double* M) {
+  const size_t n = S.ng;
+  int T = (int)std::max<size_t>(1, std::min<size_t>(4, n / 512));
+  if (const char* e = std::getenv("NNSDP_HOST_THREADS")) T = std::max(1, std::min(std::atoi(e), 16));      // (diagnostic / test)
+  auto work = [&](int t) {
+    // columns [c0, c1): the cost of a column range is ~ the lower triangle below it, so the ranges are balanced by area
+    auto cut = [&](int q) { return (size_t)((double)n * (1.0 - std::sqrt(1.0 - (double)q / T))); };
+    const size_t c0 = t == 0 ? 0 : cut(t), c1 = t == T - 1 ? n : cut(t + 1);
+    if (c1 <= c0) return;
+    std::fill(M + c0 * n, M + c1 * n, 0.0);
+    for (int e = 0; e < S.NE; ++e) {
+      const int lo = S.csr_ptr[e], hi = S.csr_ptr[e + 1];
+      const double d = S.Dinv[e];
+      for (int x = lo; x < hi; ++x) {
+        const size_t cx = S.csr_col[x];
+        if (cx < c0) continue;
+        if (cx >= c1) break;                                 // (columns of a row are sorted)
+        const double vx = d * S.csr_val[x];
+        double* col = M + cx * n;
+        for (int y = x; y < hi; ++y) col[S.csr_col[y]] += vx * S.csr_val[y];  // lower: row >= col
+      }
     }
-  }
-  for (size_t j = 0; j < n; ++j) {
-    M[j * n + j] += 1.0;
-    for (size_t i = j + 1; i < n; ++i) M[i * n + j] = M[j * n + i] = M[j * n + i] + M[i * n + j];
-  }
+    for (size_t j = c0; j < c1; ++j) M[j * n + j] += 1.0;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
 }
 
 }  // namespace nnsdp

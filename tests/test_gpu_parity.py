@@ -730,3 +730,18 @@ def test_degenerate_input_box_is_certified():
     X = np.stack([0.5 + np.random.default_rng(0).random(5000), np.ones(5000)])
     assert np.max(normal @ na.evalFeedFwdNet(net, X)) <= s.objective_value + 1e-9          # a sound bound on the slice
     assert s.values["γin"][1] > 0.0                                                          # the eliminated coordinate's multiplier
+
+
+def test_woodbury_core_does_not_depend_on_the_host_thread_count(monkeypatch):
+    """M = I + A'D^-1A is assembled by host threads that own disjoint column ranges (round 4): every entry is accumulated by one thread
+    in the row order of A, so M^-1 q must come out bit for bit the same with 1, 3 and 4 threads"""
+    import hashlib
+    q = helpers.product_query(helpers.load_problem("W40-D20", 0))
+    dig = []
+    for t in ("1", "3", "4"):
+        monkeypatch.setenv("NNSDP_HOST_THREADS", t)
+        s = na.Solver(q, na.AdmmSdpOptions(decomp_mode=na.DoubleDecomp(), minv_mode=1))
+        v = np.cos(np.arange(s.cp.ngamma) * 0.37)
+        dig.append(hashlib.sha256(s.apply_minv(v)[0].tobytes()).hexdigest())
+        s.close()
+    assert dig[0] == dig[1] == dig[2]
