@@ -368,7 +368,7 @@ def main():
                                   "note": "what bounds the kernel: one SDP's 19 blocks occupy 19 of 256 CUs and live on those CUs' fp64 matrix pipes (DESIGN.md section 4)"}},
             "eig_share_of_step": eig_avg_s / (dt / args.steps), "avg_jacobi_sweeps": sm["avg_sweeps"],
             "graph_replay": {"value": graph_ips, "unit": "ADMM iters/s", "steps": g_steps, "ms_per_step": 1e3 / graph_ips,
-                             "note": "the mode nnsdp_solve itself runs in (8 iterations per hipGraph replay, no per-launch events); `value` above is the eager rate with HIP events around every projection launch"},
+                             "note": "the mode nnsdp_solve itself runs in (7 iterations per hipGraph replay + the check iteration as a graph of its own, no per-launch events); `value` above is the eager rate with HIP events around every projection launch"},
             "graph_replay_iters_per_s": graph_ips, "graph_replay_steps_timed": g_steps,
             "refine_blocks_until_window": sm.get("refine_blocks"),
             "iterate": {"pres": pres, "dres": dres, "objective": pobj, "dual_objective": dobj},
